@@ -1,0 +1,124 @@
+"""Evaluation harness around the hot path: the caller side of `TCStereo.forward`.
+
+Counterpart of validate_tartanair / validate_temporal_things (evaluate_stereo.py:119-223,264-345):
+pads each frame (and shifts K), threads the temporal state dict through the model, and accumulates
+EPE / D1 / D3 with the reference's validity mask and mask-rate weighting.  No wandb, no datasets:
+sequences come from `tcs_mi355.synth` (or from files, when present, via `tcs_mi355.formats`).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence as Seq
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+class InputPadder:
+    """Replicate-pad [.., H, W] tensors up to a multiple of `divis_by` and move the principal point
+    of K by the left/top pad (core/utils/utils.py:7-48).  'sintel' mode splits the padding evenly,
+    any other mode pads bottom only (and left/right evenly)."""
+
+    def __init__(self, dims, mode: str = "sintel", divis_by: int = 8):
+        self.ht, self.wd = int(dims[-2]), int(dims[-1])
+        extra_h = -self.ht % divis_by
+        extra_w = -self.wd % divis_by
+        left = extra_w // 2
+        if mode == "sintel":
+            top = extra_h // 2
+        else:
+            top = 0
+        self.left, self.right, self.top, self.bottom = left, extra_w - left, top, extra_h - top
+
+    def _shift(self, K, sign):
+        K = K.clone()
+        K[..., 0, 2] += sign * self.left
+        K[..., 1, 2] += sign * self.top
+        return K
+
+    def pad(self, *tensors, K=None):
+        for t in tensors:
+            if t.ndim != 4:
+                raise ValueError("InputPadder.pad expects [N,C,H,W] tensors")
+        padded = [F.pad(t, [self.left, self.right, self.top, self.bottom], mode="replicate") for t in tensors]
+        return padded, (None if K is None else self._shift(K, +1))
+
+    def unpad(self, x, K=None):
+        if x.ndim != 4:
+            raise ValueError("InputPadder.unpad expects a [N,C,H,W] tensor")
+        h, w = x.shape[-2:]
+        y = x[..., self.top:h - self.bottom, self.left:w - self.right]
+        return y if K is None else (y, self._shift(K, -1))
+
+
+@dataclass
+class FrameStats:
+    epe: float
+    d1_weighted: float       # mean(epe>1 over valid) * mask_rate
+    d3_weighted: float
+    mask_rate: float
+
+
+@dataclass
+class SequenceStats:
+    frames: List[FrameStats] = field(default_factory=list)
+
+    def vector(self) -> np.ndarray:
+        """[sum_epe, sum_d1w, sum_d3w, sum_rate, n_frames]: what one rank contributes to the gather."""
+        if not self.frames:
+            return np.zeros(5, np.float64)
+        a = np.array([[f.epe, f.d1_weighted, f.d3_weighted, f.mask_rate, 1.0] for f in self.frames], np.float64)
+        return a.sum(0)
+
+
+def frame_metrics(disp_pr: torch.Tensor, disp_gt: torch.Tensor, max_disp: float = 192.0) -> Optional[FrameStats]:
+    """evaluate_stereo.py:201-213: per-pixel |pr-gt|, valid = |gt| < 192, outlier rates at 1 and 3 px,
+    weighted by the fraction of valid pixels.  Returns None when no pixel is valid (frame skipped)."""
+    if disp_pr.shape != disp_gt.shape:
+        raise ValueError(f"shape mismatch {tuple(disp_pr.shape)} vs {tuple(disp_gt.shape)}")
+    err = (disp_pr - disp_gt).abs().flatten()
+    valid = disp_gt.abs().flatten() < max_disp
+    if not bool(valid.any()):
+        return None
+    rate = float(valid.float().mean())
+    e = err[valid]
+    return FrameStats(float(e.mean()), float((e > 1.0).float().mean()) * rate, float((e > 3.0).float().mean()) * rate, rate)
+
+
+def reduce_stats(vectors: Seq[np.ndarray]) -> Dict[str, float]:
+    """evaluate_stereo.py:214-220: epe = mean over frames; d1 = 100*mean(out*rate)/mean(rate)."""
+    tot = np.sum(np.stack(vectors, 0), 0)
+    n = max(tot[4], 1.0)
+    rate = max(tot[3] / n, 1e-12)
+    return {"epe": tot[0] / n, "d1": 100.0 * (tot[1] / n) / rate, "d3": 100.0 * (tot[2] / n) / rate, "frames": int(tot[4])}
+
+
+@torch.no_grad()
+def run_sequence(forward: Callable, seq, iters: int, device, temporal: bool = True, divis_by: int = 32,
+                 collect: Optional[list] = None) -> SequenceStats:
+    """One video sequence through `forward(image1, image2, iters=, test_mode=True, params=)`.
+    State is reset per sequence (evaluate_stereo.py:170-174) and carried frame to frame
+    (evaluate_stereo.py:182-197).  `collect`, if given, receives each frame's unpadded prediction."""
+    stats = SequenceStats()
+    K_raw = torch.as_tensor(seq.K, dtype=torch.float32, device=device)[None]
+    baseline = torch.tensor([seq.baseline], dtype=torch.float32, device=device)
+    params: dict = {}
+    flow_q = fmap1 = prev_T = nets = None
+    for fr in seq.frames:
+        im1 = torch.as_tensor(fr.image1, device=device)[None]
+        im2 = torch.as_tensor(fr.image2, device=device)[None]
+        gt = torch.as_tensor(fr.disp_gt, device=device)[None]
+        T = torch.as_tensor(fr.T, device=device)[None]
+        padder = InputPadder(im1.shape, divis_by=divis_by)
+        (im1, im2), K = padder.pad(im1, im2, K=K_raw)
+        params.update(K=K, T=T, previous_T=prev_T, last_disp=flow_q, last_net_list=nets, fmap1=fmap1, baseline=baseline)
+        out = forward(im1, im2, iters=iters, test_mode=True, params=params if (flow_q is not None and temporal) else None)
+        flow_q, nets, fmap1, prev_T = out["flow_q"], out["net_list"], out["fmap1"], T
+        disp_pr = padder.unpad(-out["flow"])
+        if collect is not None:
+            collect.append(disp_pr)
+        fs = frame_metrics(disp_pr, gt)
+        if fs is not None:
+            stats.frames.append(fs)
+    return stats
