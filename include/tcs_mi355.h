@@ -1,0 +1,218 @@
+/*
+ * tcs_mi355.h — C ABI of libtcs_mi355.so: the TC-Stereo inference hot path on MI355X (gfx950).
+ *
+ * The reference (jiaxiZeng/Temporally-Consistent-Stereo-Matching) has no FFI layer: its "operator
+ * API" is Python call signatures over torch tensors, plus ONE native entry point, the CuPy-JIT CUDA
+ * kernel `softsplat_out(n, tenIn, tenFlow, tenOut)` (core/utils/splatting/softsplat.py:285-290).
+ * Every function below replaces one of those Python-level operators (cited per function) with a
+ * hand-written HIP kernel sequence.  The Python mirror in
+ * `temporally-consistent-stereo-matching_amd/core/` binds these with ctypes; INTEGRATION.md shows the
+ * stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - Every tensor is a raw DEVICE pointer to contiguous float32 in NCHW order unless stated.
+ *  - The caller owns every buffer, including outputs and workspaces (`*_workspace_bytes`).
+ *    Nothing is allocated, freed or synchronised inside; all work is enqueued on `stream`
+ *    (a hipStream_t passed as void*; NULL = the default stream).  Safe under HIP graph capture.
+ *  - Return value: 0 on success, negative TCS_E* otherwise.  Never throws, never exits.
+ *  - Re-entrant per stream; no global mutable state.
+ */
+#ifndef TCS_MI355_H
+#define TCS_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TCS_OK 0
+#define TCS_EINVAL (-1)      /* bad argument (null pointer, non-positive size, unsupported shape) */
+#define TCS_ELAUNCH (-2)     /* the HIP runtime rejected a launch / memset */
+#define TCS_EUNSUPPORTED (-3)
+
+typedef void* tcs_stream_t;
+
+int tcs_abi_version(void);                 /* bumped when a signature changes */
+const char* tcs_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------------
+ * Correlation volume: build, pyramid, first-frame argmax, lookup           (core/corr.py)
+ *
+ * HBM layout of the pyramid ("skewed"): level i is stored as P_i[b][h][d][w1], d in [0, W_i),
+ * W_i = W >> i, holding L_i[b][h][w1][j] at d = ((w1 >> i) - j) mod W_i.  For a smooth disparity
+ * field the 2r+2 taps of horizontally adjacent pixels then sit in the same few rows `d`, contiguous
+ * along w1, so one wavefront's loads coalesce into a handful of 256-byte segments instead of 64
+ * scattered lines (the reference layout [b][h][w1][j] puts every pixel's window in its own row).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* bytes of one skewed level i (i = 0..3) for a [B,C,H,W] feature map */
+size_t tcs_corr_level_bytes(int B, int H, int W, int level);
+/* scratch needed by tcs_corr_build (natural-layout level 0 + inverse norms) */
+size_t tcs_corr_build_workspace_bytes(int B, int H, int W);
+
+/*
+ * CorrBlock1D.__init__ + CorrBlock1D.corr (core/corr.py:8-31,54-62) and, when sparse_* are given,
+ * CorrBlock1D.argmax_disp (core/corr.py:67-79) fused into the same pass.
+ *   fmap1, fmap2 : [B,C,H,W]
+ *   pyr0..pyr3   : skewed levels (sizes from tcs_corr_level_bytes)                    (required)
+ *   nat1..nat3   : natural-layout levels [B,H,W,W>>i] as the reference stores them    (nullable; tests)
+ *                  (natural level 0 is always left in the workspace: see tcs_corr_ws_level0)
+ *   cost_volume  : [B,W,H,W] masked volume cost[b,w2,h,w1] = V*(w2<=w1), corr.py:25-31 (nullable)
+ *   sparse_disp, sparse_cost, sparse_mask : [B,1,H,W] each                             (all or none)
+ */
+int tcs_corr_build(const float* fmap1, const float* fmap2, int B, int C, int H, int W,
+                   float* pyr0, float* pyr1, float* pyr2, float* pyr3,
+                   float* nat1, float* nat2, float* nat3,
+                   float* cost_volume,
+                   float* sparse_disp, float* sparse_cost, float* sparse_mask,
+                   void* workspace, tcs_stream_t stream);
+/* pointer to the natural-layout level 0 volume [B,H,W,W] inside a build workspace */
+float* tcs_corr_ws_level0(void* workspace);
+
+/*
+ * CorrBlock1D.__call__ (core/corr.py:33-52) with bilinear_sampler (core/utils/utils.py:82-97):
+ *   coords [B,1,H,W] (x position in the right image) -> out [B, 4*(2*radius+1), H, W].
+ * Channel = level*(2r+1) + tap, taps ascending in dx; samples outside a level read 0.
+ */
+int tcs_corr_lookup(const float* pyr0, const float* pyr1, const float* pyr2, const float* pyr3,
+                    const float* coords, int B, int H, int W, int radius, float* out, tcs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Temporal warp                                 (core/utils/geo_utils.py, core/utils/splatting/softsplat.py)
+ * ---------------------------------------------------------------------------------------------- */
+size_t tcs_warp_workspace_bytes(int B, int C, int H, int W);
+
+/*
+ * warp() (geo_utils.py:158-198) = disparity -> 3-D -> relative pose -> reprojection, then
+ * softsplat(..., 'soft-clipeps', valid) (softsplat.py:232-274, kernel softsplat_out :285-335),
+ * optionally followed by the temporal matching cost of tc_stereo.py:139-140.
+ *   prev_disp [B,1,H,W] (>= 0), prev_fmap [B,C,H,W]
+ *   T_rel [B,4,4], K [B,3,3], K_inv [B,3,3] (K already scaled to the 1/4 grid), baseline [B]
+ *   out_disp [B,1,H,W], out_mask [B,1,H,W]                                   (required)
+ *   out_fmap [B,C,H,W]                                                       (nullable)
+ *   cur_fmap [B,C,H,W] + out_cost [B,1,H,W]: cosine cost vs the current frame (both or none)
+ * Float atomics are used for the splat, like the reference's atomicAdd: the summation order, and
+ * therefore the last bits, can differ from run to run.
+ */
+int tcs_warp_forward(const float* prev_disp, const float* prev_fmap, const float* T_rel, const float* K,
+                     const float* K_inv, const float* baseline, int B, int C, int H, int W,
+                     float* out_disp, float* out_fmap, float* out_mask,
+                     const float* cur_fmap, float* out_cost,
+                     void* workspace, tcs_stream_t stream);
+
+/* The pre-splat quantities of warp() (geo_utils.py:169-193), exposed for parity tests:
+ * cur_disp, valid, flow [B,2,H,W], metric — all [B,1,H,W] unless noted. */
+int tcs_warp_geometry(const float* prev_disp, const float* T_rel, const float* K, const float* K_inv,
+                      const float* baseline, int B, int H, int W,
+                      float* cur_disp, float* valid, float* flow, float* metric,
+                      void* workspace, tcs_stream_t stream);
+
+/* softsplat 'summation' core (softsplat.py:285-335): out[B,C,H,W] += bilinear splat of in along flow.
+ * `out` must be zeroed by the caller.  One thread per source pixel; 4 x C float atomics each. */
+int tcs_softsplat_sum(const float* in, const float* flow, int B, int C, int H, int W, float* out,
+                      tcs_stream_t stream);
+
+/* get_backward_grid (geo_utils.py:201-236): grid [B,2,H,W] of previous-frame pixel coordinates. */
+int tcs_backward_grid(const float* disp, const float* T_rel, const float* K, const float* K_inv,
+                      const float* baseline, int B, int H, int W, float* grid, tcs_stream_t stream);
+
+/* bilinear_sampler (core/utils/utils.py:82-97): img [B,C,Hi,Wi] sampled at grid [B,2,Ho,Wo] (x,y in
+ * pixels), zeros outside, align_corners=True -> out [B,C,Ho,Wo]. */
+int tcs_bilinear_sample(const float* img, const float* grid, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                        float* out, tcs_stream_t stream);
+
+/* 0.5 * F.interpolate(grid, scale_factor=0.5, bilinear, align_corners=True) (tc_stereo.py:163):
+ * grid [B,2,H,W] -> [B,2,H/2,W/2]. */
+int tcs_grid_halve(const float* grid, int B, int H, int W, float* out, tcs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stencils of the refinement loop
+ * ---------------------------------------------------------------------------------------------- */
+/* coords bookkeeping (tc_stereo.py:188-189): coords1 += delta; disp_q = x - coords1 (in place on coords1). */
+int tcs_flow_step(float* coords1, const float* delta, int B, int H, int W, float* disp_q, tcs_stream_t stream);
+
+/* disp2disp_gradient_xy (geo_utils.py:115-132) scaled by `scale` (the 5x of update.py:199):
+ * disp [B,1,H,W] -> grad [B,2,H,W]. */
+int tcs_disp_gradient_xy(const float* disp, int B, int H, int W, float scale, float* grad, tcs_stream_t stream);
+
+/* disp2disp_grad_candidates(level=2) (geo_utils.py:73-101) flattened as update.py:202-204:
+ * disp [B,1,H,W] -> cands [B,32,H,W], channel = comp*16 + k. */
+int tcs_grad_candidates(const float* disp, int B, int H, int W, float* cands, tcs_stream_t stream);
+
+/* DispRefine.propagate_disparity (update.py:259-289): grad [B,2,H,W], disp [B,1,H,W] ->
+ * out [B,27,H,W] = cat(candidates(9), |grad diff|(18)) — the input of disp_f_stem (update.py:295). */
+int tcs_propagate_disparity(const float* grad, const float* disp, int B, int H, int W, float* out27,
+                            tcs_stream_t stream);
+
+/* update.py:298-300 + tc_stereo.py:198-202: softmax over the 9 logits (max-subtracted), blend the 9
+ * candidates (first 9 channels of a [B,cand_ctot,H,W] buffer), and emit
+ *   refined [B,1,H,W], delta_disp = refined - disp_q [B,1,H,W] (nullable), coords1 = x - refined (nullable). */
+int tcs_softmax_blend(const float* logits9, const float* cand, int cand_ctot, const float* disp_q,
+                      int B, int H, int W, float* refined, float* delta_disp, float* coords1, tcs_stream_t stream);
+
+/* TCStereo.upsample_flow (tc_stereo.py:75-88) with factor 4, applied to flow = -disp:
+ * disp [B,1,H,W], mask [B,144,H,W] -> flow_up [B,1,4H,4W]; flow_q [B,1,H,W] = -disp (nullable).
+ * clip != 0 additionally applies the torch.clip(., max=0) of the returned dict (tc_stereo.py:223-224)
+ * to both outputs. */
+int tcs_convex_upsample(const float* disp, const float* mask, int B, int H, int W, int clip, float* flow_up, float* flow_q,
+                        tcs_stream_t stream);
+
+/* pool2x = avg_pool2d(3, stride 2, pad 1), divisor 9 everywhere (update.py:114-115): [B,C,H,W] -> [B,C,Ho,Wo],
+ * Ho = (H-1)/2+1. */
+int tcs_avgpool3s2(const float* x, int B, int C, int H, int W, float* out, tcs_stream_t stream);
+
+/* interp(): bilinear resize with align_corners=True (update.py:122-124): [B,C,H,W] -> [B,C,Ho,Wo]. */
+int tcs_resize_bilinear(const float* x, int B, int C, int H, int W, int Ho, int Wo, float* out, tcs_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolutions of the update step on the matrix cores (fp32-in / fp32-accumulate MFMA)
+ * ---------------------------------------------------------------------------------------------- */
+#define TCS_ACT_NONE 0
+#define TCS_ACT_RELU 1
+#define TCS_ACT_SIGMOID 2
+#define TCS_ACT_TANH 3
+#define TCS_ACT_LEAKY 4          /* LeakyReLU(0.01) */
+
+#define TCS_EPI_LINEAR 0         /* out = act(conv + bias + addend) * post_scale                   */
+#define TCS_EPI_GRU_ZR 1         /* first half: z = sigmoid(. + cz) -> out; second half: r = sigmoid(. + cr), out2 = r*h */
+#define TCS_EPI_GRU_Q 2          /* q = tanh(. + cq); out = blend(z, h, q)                           */
+
+#define TCS_MAX_SRC 4
+
+typedef struct tcs_conv_desc {
+    /* virtual concatenation of up to 4 NCHW sources along channels (replaces torch.cat, update.py:79-80) */
+    const float* src[TCS_MAX_SRC];
+    int src_ch[TCS_MAX_SRC];
+    int n_src;
+    const float* weight;     /* packed by tcs_pack_conv_weight */
+    const float* bias;       /* [Cout] or NULL */
+    int B, H, W;             /* stride-1 'same' convolution: output H,W = input H,W */
+    int Cin, Cout, ksize;    /* ksize in {1,3,7} */
+    int epilogue;            /* TCS_EPI_* */
+    int act;                 /* TCS_ACT_*  (LINEAR epilogue only) */
+    float post_scale;        /* LINEAR epilogue: multiplies the activated value (e.g. 0.25 of update.py:304) */
+    const float* addend;     /* LINEAR: optional [B,Cout,H,W] added before the activation.
+                                GRU_ZR: cz;  GRU_Q: cq  ([B,hidden,H,W], nullable)                   */
+    const float* addend2;    /* GRU_ZR: cr (nullable) */
+    const float* h;          /* GRU_ZR / GRU_Q: hidden state [B,hidden,H,W] */
+    const float* z;          /* GRU_Q: update gate from the ZR pass */
+    int blend_keep_z;        /* GRU_Q: 0 -> (1-z)h + zq (ConvGRU, update.py:85); 1 -> zh + (1-z)q (update.py:34,66) */
+    float* out;              /* LINEAR: [B,out_ctot,H,W] written at channel offset out_coff. GRU_ZR: z. GRU_Q: new h */
+    int out_ctot, out_coff;
+    float* out2;             /* GRU_ZR: r*h */
+} tcs_conv_desc;
+
+/* packed weight size in floats for a [Cout,Cin,k,k] convolution */
+size_t tcs_conv_packed_floats(int Cout, int Cin, int ksize);
+/* OIHW device weights -> the kernel's layout ([Cin_pad][k*k][Cout_pad], zero padded) */
+int tcs_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int ksize, float* packed, tcs_stream_t stream);
+/* nn.Conv2d(k, padding=k/2) + fused epilogue; covers ConvGRU / Lightfuse / HiddenstateUpdater /
+ * BasicMotionEncoder / FlowHead / the stride-1 convs of DispRefine and DispGradPredictor (core/update.py). */
+int tcs_conv2d(const tcs_conv_desc* desc, tcs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TCS_MI355_H */

@@ -1,0 +1,122 @@
+"""Feature / context extractors (reference: core/extractor.py).  BASELINE.json's north_star keeps
+the extractor on PyTorch-ROCm; this file only restates the module tree so that the reference's
+checkpoints load with strict=True (same attribute names, same parameter shapes)."""
+import torch
+import torch.nn as nn
+
+
+def _norm(kind, ch, stem=False):
+    if kind == "group":
+        return nn.GroupNorm(num_groups=8 if stem else ch // 8, num_channels=ch)
+    if kind == "batch":
+        return nn.BatchNorm2d(ch)
+    if kind == "instance":
+        return nn.InstanceNorm2d(ch)
+    if kind == "none":
+        return nn.Sequential()
+    raise ValueError(f"unknown norm {kind!r}")
+
+
+def _init(module, fan_mode):
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode=fan_mode, nonlinearity="relu")
+        elif isinstance(m, (nn.BatchNorm2d, nn.InstanceNorm2d, nn.GroupNorm)) and m.weight is not None:
+            nn.init.constant_(m.weight, 1)
+            nn.init.constant_(m.bias, 0)
+
+
+class ResidualBlock(nn.Module):
+    """Two 3x3 convs with a (projected, when stride or width changes) identity (extractor.py:5-58)."""
+
+    def __init__(self, in_planes, planes, norm_fn="group", stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_planes, planes, 3, padding=1, stride=stride)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+        self.norm1, self.norm2 = _norm(norm_fn, planes), _norm(norm_fn, planes)
+        self.downsample = None
+        if stride != 1 or in_planes != planes:
+            self.norm3 = _norm(norm_fn, planes)
+            self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, 1, stride=stride), self.norm3)
+
+    def forward(self, x):
+        y = self.relu(self.norm1(self.conv1(x)))
+        y = self.relu(self.norm2(self.conv2(y)))
+        skip = x if self.downsample is None else self.downsample(x)
+        return self.relu(skip + y)
+
+
+def _stage(in_planes, dim, norm_fn, stride):
+    return nn.Sequential(ResidualBlock(in_planes, dim, norm_fn, stride), ResidualBlock(dim, dim, norm_fn, 1))
+
+
+class BasicEncoder(nn.Module):
+    """Matching-feature encoder used when shared_backbone is off (extractor.py:119-192)."""
+
+    def __init__(self, output_dim=128, norm_fn="batch", dropout=0.0, downsample=3):
+        super().__init__()
+        self.norm_fn, self.downsample = norm_fn, downsample
+        self.norm1 = _norm(norm_fn, 64, stem=True)
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=1 + (downsample > 2), padding=3)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.layer1 = _stage(64, 64, norm_fn, 1)
+        self.layer2 = _stage(64, 96, norm_fn, 1 + (downsample > 1))
+        self.layer3 = _stage(96, 128, norm_fn, 1 + (downsample > 0))
+        self.conv2 = nn.Conv2d(128, output_dim, 1)
+        self.dropout = nn.Dropout2d(p=dropout) if dropout > 0 else None
+        _init(self, "fan_out")
+
+    def forward(self, x, dual_inp=False):
+        parts = None
+        if isinstance(x, (tuple, list)):
+            parts = x[0].shape[0]
+            x = torch.cat(x, 0)
+        x = self.relu1(self.norm1(self.conv1(x)))
+        x = self.conv2(self.layer3(self.layer2(self.layer1(x))))
+        if self.training and self.dropout is not None:
+            x = self.dropout(x)
+        return x.split(parts, 0) if parts is not None else x
+
+
+class MultiBasicEncoder(nn.Module):
+    """Context network with per-scale heads at 1/4, 1/8, 1/16 (the strides are fixed; the
+    08/16/32 attribute names are historical — extractor.py:195-296)."""
+
+    def __init__(self, output_dim=[128], norm_fn="batch", dropout=0.0, downsample=3):
+        super().__init__()
+        self.norm_fn, self.downsample = norm_fn, downsample
+        self.norm1 = _norm(norm_fn, 64, stem=True)
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=1, padding=3)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.layer1 = _stage(64, 64, norm_fn, 1)
+        self.layer2 = _stage(64, 96, norm_fn, 2)
+        self.layer3 = _stage(96, 128, norm_fn, 2)
+        self.layer4 = _stage(128, 128, norm_fn, 2)
+        self.layer5 = _stage(128, 128, norm_fn, 2)
+
+        def head(ch, with_block):
+            conv = nn.Conv2d(128, ch, 3, padding=1)
+            return nn.Sequential(ResidualBlock(128, 128, norm_fn, 1), conv) if with_block else conv
+
+        self.outputs08 = nn.ModuleList([head(d[2], True) for d in output_dim])
+        self.outputs16 = nn.ModuleList([head(d[1], True) for d in output_dim])
+        self.outputs32 = nn.ModuleList([head(d[0], False) for d in output_dim])
+        self.dropout = nn.Dropout2d(p=dropout) if dropout > 0 else None
+        _init(self, "fan_out")
+
+    def forward(self, x, dual_inp=False, num_layers=3):
+        x = self.relu1(self.norm1(self.conv1(x)))
+        x = self.layer3(self.layer2(self.layer1(x)))
+        tail = ()
+        if dual_inp:
+            tail = (x,)
+            x = x[: x.shape[0] // 2]
+        scales = [[f(x) for f in self.outputs08]]
+        if num_layers >= 2:
+            y = self.layer4(x)
+            scales.append([f(y) for f in self.outputs16])
+        if num_layers >= 3:
+            z = self.layer5(y)
+            scales.append([f(z) for f in self.outputs32])
+        return (*scales, *tail)

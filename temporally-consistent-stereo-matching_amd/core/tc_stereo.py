@@ -1,0 +1,169 @@
+"""Drop-in for the reference's core/tc_stereo.py: `TCStereo` with the hot path on MI355X.
+
+Same constructor (an argparse-style Namespace), same sub-module names (reference checkpoints load
+with strict=True), same `forward(image1, image2, iters, params, test_mode, frame_id)` signature and
+the same test-mode output dict, so evaluate_stereo.py's loop (evaluate_stereo.py:170-197) runs
+unchanged.  What differs is underneath: correlation build/lookup, the temporal warp, the GRU update
+step and every stencil are hand-written HIP kernels for gfx950 (libtcs_mi355.so); only the feature
+extractor and the once-per-frame U-Nets remain PyTorch-ROCm modules.
+
+Inference only: `test_mode=False` (training outputs and losses, train_stereo.py) is out of scope.
+There is no CPU path: tensors must live on a HIP device and the library must be built.
+"""
+import contextlib
+
+import torch
+import torch.nn as nn
+
+from core.corr import CorrBlock1D
+from core.extractor import BasicEncoder, MultiBasicEncoder, ResidualBlock
+from core.update import (BasicMultiUpdateBlock, DispGradPredictor, DispRefine, DisparityCompletor, HiddenstateUpdater,
+                         Lightfuse, hip_conv)
+from core.utils.utils import coords_grid
+from tcs_mi355 import ops
+
+
+class autocast(contextlib.AbstractContextManager):
+    """evaluate_stereo.py imports `autocast` from here (evaluate_stereo.py:14).  The HIP path computes
+    in fp32 (MFMA fp32-in/fp32-acc), so this is a no-op context whatever `enabled` says."""
+
+    def __init__(self, enabled=False, **_):
+        self.enabled = enabled
+
+    def __exit__(self, *exc):
+        return False
+
+
+class TCStereo(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.scale_rate = 1 / (2 ** args.n_downsample)
+        hd = list(args.hidden_dims)
+        n = args.n_gru_layers
+        self.cnet = MultiBasicEncoder(output_dim=[hd, hd], norm_fn=args.context_norm, downsample=args.n_downsample)
+        self.update_block = BasicMultiUpdateBlock(args, hidden_dims=hd)
+        self.context_zqr_convs = nn.ModuleList([nn.Conv2d(hd[i], hd[i] * 3, 3, padding=1) for i in range(n)])
+        if args.shared_backbone:
+            self.conv2 = nn.Sequential(ResidualBlock(128, 128, "instance", stride=1), nn.Conv2d(128, 256, 3, padding=1))
+        else:
+            self.fnet = BasicEncoder(output_dim=256, norm_fn="instance", downsample=args.n_downsample)
+        self.previous_current_hideen_fuse = nn.ModuleList([Lightfuse(hd[i], hd[i]) for i in range(n)])   # (sic)
+        self.disp_completor = DisparityCompletor()
+        self.disp_grad_refine = DispGradPredictor(args)
+        self.disp_refine = DispRefine(args)
+        self.context_zqr_convs_grad = nn.ModuleList([nn.Conv2d(hd[i], 64, 3, padding=1) for i in range(n)])
+        self.hiddenstate_update = HiddenstateUpdater(hd[0])
+
+    def freeze_bn(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.eval()
+
+    def initialize_flow(self, img):
+        """coords0, coords1: the x-coordinate grid at feature resolution, [N,1,H,W] each (tc_stereo.py:66-73)."""
+        n, _, h, w = img.shape
+        g = coords_grid(n, h, w, device=img.device)[:, :1].contiguous()
+        return g, g.clone()
+
+    def upsample_flow(self, flow, mask, scale=True):
+        """Convex x4 upsampling (tc_stereo.py:75-88).  Returns the upsampled flow (not clipped)."""
+        if not scale or self.args.n_downsample != 2:
+            raise NotImplementedError("HIP convex upsampling covers factor 4 with scaling")
+        up, _ = ops.convex_upsample((-flow).float().contiguous(), mask.float().contiguous(), clip=False)   # kernel takes disparity
+        return up
+
+    def fuse_previous_current_hidden_state(self, net_list, warp_net_list):
+        return [fuse(n, w) for n, w, fuse in zip(net_list, warp_net_list, self.previous_current_hideen_fuse)]
+
+    # -----------------------------------------------------------------------------------------
+    def _extract(self, image1, image2):
+        a = self.args
+        if a.shared_backbone:
+            *cnet_list, trunk = self.cnet(torch.cat((image1, image2), 0), dual_inp=True, num_layers=a.n_gru_layers)
+            fmap1, fmap2 = self.conv2(trunk).split(trunk.shape[0] // 2, 0)
+        else:
+            cnet_list = self.cnet(image1, num_layers=a.n_gru_layers)
+            fmap1, fmap2 = self.fnet([image1, image2])
+        return list(cnet_list), fmap1.float().contiguous(), fmap2.float().contiguous()
+
+    @torch.no_grad()
+    def forward(self, image1, image2, iters=12, params=None, test_mode=False, frame_id=0):
+        """Disparity of a stereo pair, optionally conditioned on the previous frame (`params`):
+        K [b,3,3], T / previous_T [b,4,4] world->camera, baseline [b], last_disp (= previous 'flow_q'),
+        last_net_list, fmap1.  Returns {'flow' [b,1,H,W] (negative disparity, clipped at 0),
+        'flow_q' [b,1,H/4,W/4], 'net_list', 'fmap1'} (tc_stereo.py:96-244)."""
+        if not test_mode:
+            raise NotImplementedError("TCStereo on MI355X is inference-only: call with test_mode=True")
+        if iters < 1:
+            raise ValueError("iters must be >= 1")
+        if not image1.is_cuda:
+            raise RuntimeError("TCStereo.forward needs HIP device tensors; there is no CPU fallback")
+        a = self.args
+        image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
+        image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
+        cnet_list, fmap1, fmap2 = self._extract(image1, image2)
+
+        first = params is None
+        corr_fn = CorrBlock1D(fmap1, fmap2, radius=a.corr_radius, num_levels=a.corr_levels, thres=a.init_thres,
+                              want_argmax=first)
+        if first:
+            sparse_disp, cost, sparse_mask = corr_fn.argmax_disp()
+            last_net_list = None
+        else:
+            K = params["K"]
+            K_scale = K * torch.tensor([self.scale_rate, self.scale_rate, 1.0], device=K.device).view(1, 3, 1)
+            K_scale_inv = torch.linalg.inv(K_scale)
+            T, previous_T, baseline = params["T"], params["previous_T"], params["baseline"]
+            relative_T = torch.matmul(T, torch.linalg.inv(previous_T))
+            last_net_list = params["last_net_list"]
+            # warp + normalise + cosine cost in one launch sequence; the warped feature map is never materialised
+            sparse_disp, _, sparse_mask, cost = ops.warp_forward(
+                (-params["last_disp"]).float().contiguous(), params["fmap1"].float().contiguous(), relative_T, K_scale,
+                K_scale_inv, baseline, cur_fmap=fmap1, want_fmap=False)
+
+        inp_list = [torch.relu(x[1]) for x in cnet_list]
+        grad_list = [hip_conv(conv, [i]) for i, conv in zip(inp_list, self.context_zqr_convs_grad)]
+        inp_list = [[c.contiguous() for c in hip_conv(conv, [i]).chunk(3, 1)] for i, conv in zip(inp_list, self.context_zqr_convs)]
+        net_list = [x[0] for x in cnet_list]
+
+        disp_init, _, _, net_list = self.disp_completor(sparse_disp, cost, sparse_mask, net_list)
+        disp_init = disp_init.float().contiguous()
+
+        if last_net_list is None:
+            warped = [torch.zeros_like(x) for x in net_list]
+        else:
+            back_T = torch.matmul(previous_T, torch.linalg.inv(T))
+            grid = ops.backward_grid(disp_init, back_T, K_scale, K_scale_inv, baseline)
+            warped = []
+            for i, net in enumerate(last_net_list):
+                warped.append(ops.bilinear_sample(net.float().contiguous(), grid))
+                if i + 1 < len(last_net_list):
+                    grid = ops.grid_halve(grid)
+
+        net_list = self.fuse_previous_current_hidden_state([torch.tanh(x) for x in net_list], warped)
+
+        coords0, coords1 = self.initialize_flow(fmap1)
+        coords1 = (coords0 - disp_init).contiguous()
+
+        n3 = a.n_gru_layers == 3
+        refined = up_mask = None
+        for itr in range(iters):
+            corr = corr_fn(coords1)
+            flows_x = coords1 - coords0
+            if n3 and a.slow_fast_gru:
+                net_list = self.update_block(net_list, inp_list, iter32=True, iter16=False, iter08=False, update=False)
+            if a.n_gru_layers >= 2 and a.slow_fast_gru:
+                net_list = self.update_block(net_list, inp_list, iter32=n3, iter16=True, iter08=False, update=False)
+            net_list, delta_flow = self.update_block(net_list, inp_list, corr, flows_x, iter32=n3, iter16=a.n_gru_layers >= 2)
+            disp_q = ops.flow_step(coords1, delta_flow)                        # coords1 += delta; disp_q = x - coords1
+            disp_grad = ops.disp_gradient_xy(disp_q)
+            disp_grad, context = self.disp_grad_refine(disp_grad, disp_q, grad_list)
+            last = itr == iters - 1
+            refined, up_mask = self.disp_refine(disp_grad, disp_q, net_list[0], context, test_mode=not last)
+            delta_disp = refined - disp_q
+            net_list = [self.hiddenstate_update(net_list[0], delta_disp), net_list[1], net_list[2]]
+            coords1 = (coords0 - refined).contiguous()
+
+        flow_up, flow_q = ops.convex_upsample(refined.contiguous(), up_mask)
+        return {"flow": flow_up, "flow_q": flow_q, "net_list": [x.detach() for x in net_list], "fmap1": fmap1.detach()}

@@ -1,0 +1,317 @@
+"""Drop-in for the reference's core/update.py: the refinement-loop blocks on the HIP library.
+
+Module and parameter names equal the reference's, so `load_state_dict(strict=True)` accepts its
+checkpoints; `nn.Conv2d` objects are kept as parameter containers only.  Their forward passes run
+through `tcs_conv2d` (fp32 MFMA implicit GEMM with virtual concat and fused epilogues), so a
+ConvGRU is two launches instead of ~15 ATen ops, and the 24 host-synchronising NaN asserts per
+iteration of the reference (update.py:27-35,58-67,78-86,155-158) are gone.
+
+Still on PyTorch-ROCm (MIOpen) for now: the stride-2 convs and the transposed-conv + InstanceNorm
+up-blocks of the two U-Nets (DispGradPredictor, DisparityCompletor) — SURVEY.md §8f N3/N4.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from core.utils.basic_layers import Conv2x_IN
+from tcs_mi355 import ops
+
+
+# ---------------------------------------------------------------------------------------------
+# packed-weight cache: one device-side repack per conv, redone only if the parameter changes
+# ---------------------------------------------------------------------------------------------
+def packed(conv: nn.Conv2d) -> ops.PackedConv:
+    w, b = conv.weight, conv.bias
+    key = (w.data_ptr(), w._version, w.device, None if b is None else (b.data_ptr(), b._version))
+    hit = getattr(conv, "_tcs_packed", None)
+    if hit is None or hit[0] != key:
+        if conv.stride != (1, 1) or conv.dilation != (1, 1) or conv.groups != 1 or conv.padding != (conv.kernel_size[0] // 2,) * 2:
+            raise NotImplementedError(f"tcs_conv2d covers stride-1 'same' convolutions, got {conv}")
+        hit = (key, ops.pack_conv(w, b))
+        conv._tcs_packed = hit
+    return hit[1]
+
+
+def hip_conv(conv, srcs, act="none", **kw):
+    return ops.conv2d(packed(conv), [s.float().contiguous() for s in srcs], act=act, **kw)
+
+
+def hip_seq(seq: nn.Sequential, srcs, last_act="none"):
+    """conv -> ReLU -> conv chains declared as nn.Sequential(conv, ReLU, conv[, ReLU|Sigmoid])."""
+    x = list(srcs)
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        conv = mods[i]
+        act = "none"
+        if i + 1 < len(mods) and not isinstance(mods[i + 1], nn.Conv2d):
+            nxt = mods[i + 1]
+            act = {nn.ReLU: "relu", nn.LeakyReLU: "leaky", nn.Sigmoid: "sigmoid"}[type(nxt)]
+            i += 1
+        x = [hip_conv(conv, x, act=act)]
+        i += 1
+    return x[0]
+
+
+def _conv(cin, cout, k, stride=1):
+    return nn.Conv2d(cin, cout, k, stride, k // 2)
+
+
+def _two(cin, mid, cout, k=3, tail=None):
+    layers = [_conv(cin, mid, k), nn.ReLU(inplace=True), _conv(mid, cout, k)]
+    return nn.Sequential(*layers, *([tail] if tail is not None else []))
+
+
+# ---------------------------------------------------------------------------------------------
+# recurrent cells
+# ---------------------------------------------------------------------------------------------
+class _GateCell(nn.Module):
+    """z,r = sigma(conv_zr[h,x] (+cz,cr)); q = tanh(conv_q[r*h,x] (+cq)); blend (update.py:26-36,77-87)."""
+    keep_z = False          # False: h' = (1-z)h + zq ; True: h' = zh + (1-z)q
+
+    def __init__(self, hidden_dim, input_dim, kernel_size):
+        super().__init__()
+        self.convzr = _conv(hidden_dim + input_dim, hidden_dim * 2, kernel_size)
+        self.convq = _conv(hidden_dim + input_dim, hidden_dim, kernel_size)
+
+    def _step(self, h, xs, cz=None, cr=None, cq=None):
+        h = h.float().contiguous()
+        xs = [x.float().contiguous() for x in xs]
+        z, rh = ops.gru_gates(packed(self.convzr), [h, *xs], h, cz, cr)
+        return ops.gru_update(packed(self.convq), [rh, *xs], h, z, cq, keep_z=self.keep_z)
+
+
+class ConvGRU(_GateCell):
+    def __init__(self, hidden_dim, input_dim, kernel_size=3):
+        super().__init__(hidden_dim, input_dim, kernel_size)
+
+    def forward(self, h, cz, cr, cq, *x_list):
+        return self._step(h, x_list, cz.contiguous(), cr.contiguous(), cq.contiguous())
+
+
+class Lightfuse(_GateCell):
+    keep_z = True
+
+    def __init__(self, hidden_dim, input_dim):
+        super().__init__(hidden_dim, input_dim, 1)
+
+    def forward(self, h, x):
+        return self._step(h, [x])
+
+
+class Hardfuse(nn.Module):          # unused by the model (update.py:39-45); kept for API parity
+    def forward(self, h, x, mask):
+        return mask * h + (1 - mask) * x
+
+
+class HiddenstateUpdater(_GateCell):
+    keep_z = True
+
+    def __init__(self, hidden_dim):
+        super().__init__(hidden_dim, 64, 1)
+        self.convs = nn.Sequential(_conv(1, 64, 1), nn.LeakyReLU(inplace=True), _conv(64, 64, 1))
+
+    def forward(self, h, x):
+        return self._step(h, [hip_seq(self.convs, [x])])
+
+
+# ---------------------------------------------------------------------------------------------
+# disparity-space update block
+# ---------------------------------------------------------------------------------------------
+class FlowHead(nn.Module):
+    def __init__(self, input_dim=128, hidden_dim=256, output_dim=2):
+        super().__init__()
+        self.conv1 = _conv(input_dim, hidden_dim, 3)
+        self.conv2 = _conv(hidden_dim, output_dim, 3)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        return hip_conv(self.conv2, [hip_conv(self.conv1, [x], act="relu")])
+
+
+class BasicMotionEncoder(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        planes = args.corr_levels * (2 * args.corr_radius + 1)
+        self.convc1 = _conv(planes, 64, 1)
+        self.convc2 = _conv(64, 64, 3)
+        self.convf1 = _conv(1, 64, 7)
+        self.convf2 = _conv(64, 64, 3)
+        self.conv = _conv(128, 127, 3)
+
+    def forward(self, flow, corr):
+        flow = flow.float().contiguous()
+        cor = hip_conv(self.convc2, [hip_conv(self.convc1, [corr], act="relu")], act="relu")
+        flo = hip_conv(self.convf2, [hip_conv(self.convf1, [flow], act="relu")], act="relu")
+        n, _, h, w = flow.shape
+        out = torch.empty(n, 128, h, w, dtype=torch.float32, device=flow.device)
+        hip_conv(self.conv, [cor, flo], act="relu", out=out)     # channels 0..126 in place: no torch.cat
+        out[:, 127:128].copy_(flow)
+        return out
+
+
+def pool2x(x):
+    return ops.avgpool3s2(x.float().contiguous())
+
+
+def pool4x(x):
+    return F.avg_pool2d(x, 5, stride=4, padding=1)     # unused by the model (update.py:118-119)
+
+
+def interp(x, dest):
+    return ops.resize_bilinear(x.float().contiguous(), int(dest.shape[2]), int(dest.shape[3]))
+
+
+class BasicMultiUpdateBlock(nn.Module):
+    def __init__(self, args, hidden_dims=[]):
+        super().__init__()
+        self.args = args
+        self.encoder = BasicMotionEncoder(args)
+        n = args.n_gru_layers
+        self.gru08 = ConvGRU(hidden_dims[2], 128 + hidden_dims[1] * (n > 1))
+        self.gru16 = ConvGRU(hidden_dims[1], hidden_dims[0] * (n == 3) + hidden_dims[2])
+        self.gru32 = ConvGRU(hidden_dims[0], hidden_dims[1])
+        self.flow_head = FlowHead(hidden_dims[2], hidden_dim=256, output_dim=1)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_in", nonlinearity="relu")
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def forward(self, net, inp, corr=None, flow=None, iter08=True, iter16=True, iter32=True, update=True):
+        """Coarse-to-fine GRU sweep (update.py:145-168); `net` is updated in place like the reference."""
+        n = self.args.n_gru_layers
+        if iter32:
+            net[2] = self.gru32(net[2], *inp[2], pool2x(net[1]))
+        if iter16:
+            extra = (interp(net[2], net[1]),) if n > 2 else ()
+            net[1] = self.gru16(net[1], *inp[1], pool2x(net[0]), *extra)
+        if iter08:
+            motion = self.encoder(flow, corr)
+            extra = (interp(net[1], net[0]),) if n > 1 else ()
+            net[0] = self.gru08(net[0], *inp[0], motion, *extra)
+        if not update:
+            return net
+        return net, self.flow_head(net[0])
+
+
+# ---------------------------------------------------------------------------------------------
+# gradient-space refinement
+# ---------------------------------------------------------------------------------------------
+class DispGradPredictor(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.conv_grad_stem = _two(2, 32, 32)
+        self.conv_grad_candidate_stem = _two(32, 64, 64)
+        relu = lambda: nn.ReLU(inplace=True)
+        self.conv_4_4 = nn.Sequential(_conv(160, 64, 3), relu())
+        self.conv_4_8 = nn.Sequential(_conv(64, 96, 3, 2), relu())
+        self.conv_8_8 = nn.Sequential(_conv(160, 96, 3), relu())
+        self.conv_8_16 = nn.Sequential(_conv(96, 128, 3, 2), relu())
+        self.conv_16_16 = nn.Sequential(_conv(192, 128, 3), relu())
+        self.conv_16_8 = Conv2x_IN(128, 96, deconv=True, concat=False, keep_concat=False, IN=False)
+        self.conv_8_4 = Conv2x_IN(96, 64, deconv=True, concat=False, keep_concat=False, IN=False)
+        self.residual_head = _two(64, 128, 2)
+        self.conv_out = nn.Sequential(_conv(64, 64, 3), relu())
+
+    def _up(self, block: Conv2x_IN, x, rem):
+        """Conv2x_IN with the transposed conv + InstanceNorm on MIOpen and the 3x3 conv2 on MFMA."""
+        y = block.conv1(x)
+        if y.shape != rem.shape:
+            y = F.interpolate(y, size=rem.shape[-2:], mode="nearest")
+        return hip_conv(block.conv2.conv, [(y + rem)], act="leaky")
+
+    def forward(self, disp_grad, disp, clist):
+        disp = disp.float().contiguous()
+        g5 = (5 * disp_grad).contiguous()                        # update.py:199
+        cands = ops.grad_candidates(disp)                        # [N,32,H,W] (update.py:202-204)
+        x4_grad = hip_seq(self.conv_grad_stem, [g5])
+        x4_cand = hip_seq(self.conv_grad_candidate_stem, [cands])
+        x4 = hip_seq(self.conv_4_4, [x4_grad, x4_cand, clist[0]])
+        x8 = self.conv_4_8(x4)                                    # stride 2: MIOpen
+        x8 = hip_seq(self.conv_8_8, [x8, clist[1]])
+        x16 = self.conv_8_16(x8)                                  # stride 2: MIOpen
+        x16 = hip_seq(self.conv_16_16, [x16, clist[2]])
+        x8_up = self._up(self.conv_16_8, x16, x8)
+        x4_up = self._up(self.conv_8_4, x8_up, x4)
+        res = hip_seq(self.residual_head, [x4_up])
+        return (g5 + res) / 5, hip_seq(self.conv_out, [x4_up])
+
+
+class DispRefine(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.context_compress = _two(192, 96, 96)
+        self.disp_f_stem = _two(27, 96, 96, k=1)
+        self.conv_fuse = _two(192, 128, 128, tail=nn.ReLU(inplace=True))
+        self.w_head = nn.Sequential(_conv(128, 128, 3), nn.ReLU(inplace=True), _conv(128, 9, 1))
+        factor = 2 ** args.n_downsample
+        self.mask = nn.Sequential(_conv(128, 256, 3), nn.ReLU(inplace=True), _conv(256, factor * factor * 9, 1))
+
+    def _prop(self, disparity_grad, disparity_map):
+        return ops.propagate_disparity(disparity_grad.float().contiguous(), disparity_map.float().contiguous())
+
+    def propagate_disparity(self, disparity_grad, disparity_map):
+        """9 gradient-extrapolated neighbour candidates + 18 gradient differences (update.py:259-289)."""
+        buf = self._prop(disparity_grad, disparity_map)
+        return buf[:, :9], buf[:, 9:]
+
+    def forward(self, disp_grads, disp, context_disp, context_grad, test_mode=False):
+        disp = disp.float().contiguous()
+        context = hip_seq(self.context_compress, [context_disp, context_grad])
+        feats27 = self._prop(disp_grads, disp)                    # cat(candidates, matrix) laid out by the kernel
+        disp_f = hip_seq(self.disp_f_stem, [feats27])
+        fused = hip_seq(self.conv_fuse, [disp_f, context])
+        logits = hip_seq(self.w_head, [fused])
+        refined, _ = ops.softmax_blend(logits, feats27)
+        mask = None
+        if not test_mode:
+            mask = hip_conv(self.mask[2], [hip_conv(self.mask[0], [fused], act="relu")], post_scale=0.25)
+        return refined, mask
+
+
+# ---------------------------------------------------------------------------------------------
+# temporal disparity completion (once per frame; PyTorch-ROCm for now — SURVEY.md §8a row a9)
+# ---------------------------------------------------------------------------------------------
+class DisparityCompletor(nn.Module):
+    def __init__(self):
+        super().__init__()
+        relu = lambda: nn.ReLU(inplace=True)
+        mlp = lambda cin, mid, cout: nn.Sequential(_conv(cin, mid, 1), relu(), _conv(mid, cout, 1))
+        cin_block = lambda cin, mid, cout, s=1: nn.Sequential(_conv(cin, mid, 3, s), nn.InstanceNorm2d(mid), relu(), _conv(mid, cout, 3))
+        self.conv_disp_stem = mlp(1, 64, 64)
+        self.conv_cost_stem = mlp(1, 32, 32)
+        self.conv_mask_stem = mlp(1, 32, 32)
+        self.conv_disp_fuse = mlp(128, 128, 64)
+        self.conv_4_4 = cin_block(192, 192, 64)
+        self.conv_4_8 = cin_block(64, 64, 64, 2)
+        self.conv_8_8 = cin_block(192, 192, 64)
+        self.conv_8_16 = cin_block(64, 64, 64, 2)
+        self.conv_16_16 = cin_block(192, 192, 64)
+        self.conv_16_8 = Conv2x_IN(64, 64, deconv=True, concat=False, keep_concat=False, IN=True)
+        self.conv_8_4 = Conv2x_IN(64, 64, deconv=True, concat=False, keep_concat=False, IN=True)
+        self.disp_head = _two(64, 128, 1)
+        self.w_head = _two(64, 128, 1, tail=nn.Sigmoid())
+        self.conv_out16_disp = cin_block(192, 192, 128)
+        self.conv_out8_disp = cin_block(192, 192, 128)
+        self.conv_out4_disp = cin_block(192, 192, 128)
+
+    def forward(self, disp, cost, mask, context_list):
+        d = disp / 10
+        x4_disp = self.conv_disp_fuse(torch.cat((self.conv_disp_stem(d), self.conv_cost_stem(cost),
+                                                 self.conv_mask_stem(mask - 0.5)), 1))
+        x4 = self.conv_4_4(torch.cat((x4_disp, context_list[0]), 1))
+        x8 = self.conv_8_8(torch.cat((self.conv_4_8(x4), context_list[1]), 1))
+        x16_out = self.conv_16_16(torch.cat((self.conv_8_16(x8), context_list[2]), 1))
+        x8_out = self.conv_16_8(x16_out, x8)
+        x4_out = self.conv_8_4(x8_out, x4)
+        disp_mono = self.disp_head(x4_out)
+        w = self.w_head(x4_out)
+        completed = (w * d + (1 - w) * disp_mono) * 10
+        nets = [head(torch.cat((x, c), 1)) for head, x, c in
+                ((self.conv_out4_disp, x4_out, context_list[0]), (self.conv_out8_disp, x8_out, context_list[1]),
+                 (self.conv_out16_disp, x16_out, context_list[2]))]
+        return completed, disp_mono * 10, w, nets

@@ -1,0 +1,301 @@
+// Convolutions of the TC-Stereo update step on the gfx950 matrix cores.
+//
+// Implicit GEMM, D[cout][pixel] = sum_k W[cout][k] * X[k][pixel], k = (channel, tap), computed with
+// v_mfma_f32_32x32x2_f32: fp32 operands, fp32 accumulation, bit-for-bit an fmaf chain, so results
+// stay within summation-order noise of the reference's fp32 CPU convolutions.
+//
+//   - A operand (weights)  lane l: W[cout = l&31][k = l>>5]   -> ds_read_b32, 32 consecutive floats per half
+//   - B operand (input)    lane l: X[k = l>>5][pixel = l&31]   -> ds_read_b32, 32 consecutive floats per half
+//   - D: lane holds pixel (l&31); registers walk 16 output channels -> NCHW stores are 128-B rows.
+//
+// A block owns a 4-row x 32-column patch of one image and NT = 32*MT output channels; wave w owns
+// patch row w.  The input halo tile and the weight slice of one channel chunk are staged through
+// LDS; the 9 taps of a 3x3 filter re-read the same LDS tile at shifted offsets, so HBM/L2 sees each
+// input element once per block.  torch.cat of the reference (update.py:79-80,84) is virtual: the
+// staging loop walks up to four source tensors.  Bias, context addends, activations and the GRU
+// gate arithmetic (update.py:81-85, 30-34, 62-66) run in the epilogue on the accumulators.
+//
+// Block -> (patch, cout tile): cout tile = blockIdx.x % n_tiles.  Blocks b and b+8 share an XCD
+// (round-robin dispatch), so with 1, 2, 4 or 8 cout tiles every XCD's L2 holds a single weight slice.
+#include "tcs_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+    const float* src[TCS_MAX_SRC];
+    int src_ch[TCS_MAX_SRC];
+    int src_end[TCS_MAX_SRC];
+    const float* w;
+    const float* bias;
+    int B, H, W, Cin, Cout, CoutPad;
+    int act;
+    float post_scale;
+    const float* add1;
+    const float* add2;
+    const float* h;
+    const float* z;
+    int keep_z, hidden;
+    float* out;
+    int out_ctot, out_coff;
+    float* out2;
+    int npx, npatch, nct;
+};
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case TCS_ACT_RELU: return fmaxf(v, 0.f);
+        case TCS_ACT_SIGMOID: return sigmoidf_(v);
+        case TCS_ACT_TANH: return tanhf(v);
+        case TCS_ACT_LEAKY: return v > 0.f ? v : 0.01f * v;
+        default: return v;
+    }
+}
+
+static inline int cout_tile(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
+static inline int round_up(int a, int m) { return (a + m - 1) / m * m; }
+
+template <int KS, int MT, int KC, int EPI>
+__global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a) {
+    constexpr int NT = 32 * MT, HALO = KS / 2, IH = 4 + KS - 1, IW = 32 + KS - 1, TAPS = KS * KS;
+    constexpr int IN_CH = IH * IW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* s_in = lds;                       // [KC][IH][IW]
+    float* s_w = lds + ((KC * IN_CH + 3) & ~3);   // [KC][TAPS][NT], 16-B aligned
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = blockIdx.x;
+    const int ct = bid % a.nct, patch = bid / a.nct;
+    const int b = blockIdx.y;
+    const int y0 = (patch / a.npx) * 4, x0 = (patch % a.npx) * 32;
+    const int H = a.H, W = a.W;
+    const size_t HW = (size_t)H * W;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+
+    const int cin_loop = (a.Cin + KC - 1) / KC * KC;
+    for (int c0 = 0; c0 < cin_loop; c0 += KC) {
+        __syncthreads();
+        // ---- stage the input halo tile of KC channels (virtual concat over the sources) ----
+        for (int idx = tid; idx < KC * IN_CH; idx += 256) {
+            const int k = idx / IN_CH, rem = idx - k * IN_CH;
+            const int r = rem / IW, cc = rem - r * IW;
+            const int gy = y0 - HALO + r, gx = x0 - HALO + cc, g = c0 + k;
+            float v = 0.f;
+            if (g < a.Cin && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const float* sp = a.src[0];
+                int cb = 0, cs = a.src_ch[0];
+                if (g >= a.src_end[0]) { sp = a.src[1]; cb = a.src_end[0]; cs = a.src_ch[1]; }
+                if (g >= a.src_end[1]) { sp = a.src[2]; cb = a.src_end[1]; cs = a.src_ch[2]; }
+                if (g >= a.src_end[2]) { sp = a.src[3]; cb = a.src_end[2]; cs = a.src_ch[3]; }
+                v = sp[((size_t)b * cs + (g - cb)) * HW + (size_t)gy * W + gx];
+            }
+            s_in[idx] = v;
+        }
+        // ---- stage the weight slice: KC*TAPS rows of NT floats, 16 B per lane ----
+        {
+            const float* wsrc = a.w + (size_t)c0 * TAPS * a.CoutPad + ct * NT;
+            for (int idx = tid; idx < KC * TAPS * (NT / 4); idx += 256) {
+                const int row = idx / (NT / 4), q = idx - row * (NT / 4);
+                const float4 val = *reinterpret_cast<const float4*>(wsrc + (size_t)row * a.CoutPad + q * 4);
+                *reinterpret_cast<float4*>(s_w + row * NT + q * 4) = val;
+            }
+        }
+        __syncthreads();
+        // ---- MFMA over (tap, channel pair) ----
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            const int dy = t / KS, dx = t % KS;
+            const float* pin = s_in + (wave + dy) * IW + dx + l31 + half * IN_CH;
+            const float* pw = s_w + (half * TAPS + t) * NT + l31;
+#pragma unroll
+            for (int kk = 0; kk < KC; kk += 2) {
+                const float bv = pin[kk * IN_CH];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const float av = pw[kk * TAPS * NT + m * 32];
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[m], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue ----
+    const int px = x0 + l31, py = y0 + wave;
+    if (px >= W || py >= H) return;
+    const size_t pix = (size_t)py * W + px;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int co = ct * NT + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+            if (co >= a.Cout) continue;
+            float v = acc[m][reg] + (a.bias ? a.bias[co] : 0.f);
+            if (EPI == TCS_EPI_LINEAR) {
+                if (a.add1) v += a.add1[((size_t)b * a.Cout + co) * HW + pix];
+                v = apply_act(v, a.act) * a.post_scale;
+                a.out[((size_t)b * a.out_ctot + a.out_coff + co) * HW + pix] = v;
+            } else if (EPI == TCS_EPI_GRU_ZR) {
+                if (co < a.hidden) {
+                    const size_t o = ((size_t)b * a.hidden + co) * HW + pix;
+                    if (a.add1) v += a.add1[o];
+                    a.out[o] = sigmoidf_(v);
+                } else {
+                    const size_t o = ((size_t)b * a.hidden + (co - a.hidden)) * HW + pix;
+                    if (a.add2) v += a.add2[o];
+                    a.out2[o] = sigmoidf_(v) * a.h[o];
+                }
+            } else {
+                const size_t o = ((size_t)b * a.hidden + co) * HW + pix;
+                if (a.add1) v += a.add1[o];
+                const float q = tanhf(v), zz = a.z[o], hh = a.h[o];
+                a.out[o] = a.keep_z ? zz * hh + (1.f - zz) * q : (1.f - zz) * hh + zz * q;
+            }
+        }
+    }
+}
+
+// Single-input-channel convolutions (BasicMotionEncoder.convf1 7x7, HiddenstateUpdater.convs.0 1x1):
+// K is too small for the matrix cores to pay; one thread per pixel, 16 output channels per block.z,
+// weights are wave-uniform (scalar loads).
+template <int KS>
+__global__ __launch_bounds__(256) void k_conv_cin1(ConvArgs a) {
+    constexpr int HALO = KS / 2, TAPS = KS * KS;
+    const int b = blockIdx.y, H = a.H, W = a.W;
+    const int HW = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const int y = p / W, x = p - y * W;
+    const float* s = a.src[0] + (size_t)b * HW;
+    float in[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+        const int yy = y + t / KS - HALO, xx = x + t % KS - HALO;
+        in[t] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? s[yy * W + xx] : 0.f;
+    }
+    const int co_lo = blockIdx.z * 16, co_hi = min(a.Cout, co_lo + 16);
+    for (int co = co_lo; co < co_hi; ++co) {
+        float v = 0.f;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) v = fmaf(a.w[(size_t)t * a.CoutPad + co], in[t], v);
+        v += a.bias ? a.bias[co] : 0.f;
+        if (a.add1) v += a.add1[((size_t)b * a.Cout + co) * HW + p];
+        a.out[((size_t)b * a.out_ctot + a.out_coff + co) * HW + p] = apply_act(v, a.act) * a.post_scale;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ w, int Cout, int Cin, int taps, int CinPad, int CoutPad,
+                                                     float* __restrict__ packed) {
+    const size_t n = (size_t)CinPad * taps * CoutPad;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int co = (int)(i % CoutPad);
+    const int t = (int)((i / CoutPad) % taps);
+    const int ci = (int)(i / ((size_t)CoutPad * taps));
+    packed[i] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * taps + t] : 0.f;
+}
+
+template <int KS, int MT, int KC, int EPI>
+static int launch_mfma(const ConvArgs& a, hipStream_t s) {
+    constexpr int IH = 4 + KS - 1, IW = 32 + KS - 1, TAPS = KS * KS, NT = 32 * MT;
+    const size_t lds = ((size_t)((KC * IH * IW + 3) & ~3) + (size_t)KC * TAPS * NT) * sizeof(float);
+    auto kern = k_conv_mfma<KS, MT, KC, EPI>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return TCS_ELAUNCH;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.npatch * a.nct, a.B), dim3(256), lds, s, a);
+    return tcs_launch_status();
+}
+
+template <int KS, int KC, int EPI>
+static int launch_by_tile(const ConvArgs& a, int nt, hipStream_t s) {
+    switch (nt) {
+        case 128: return launch_mfma<KS, 4, KC, EPI>(a, s);
+        case 64: return launch_mfma<KS, 2, KC, EPI>(a, s);
+        default: return launch_mfma<KS, 1, KC, EPI>(a, s);
+    }
+}
+
+extern "C" {
+
+size_t tcs_conv_packed_floats(int Cout, int Cin, int ksize) {
+    if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3 && ksize != 7)) return 0;
+    return (size_t)round_up(Cin, 32) * ksize * ksize * round_up(Cout, cout_tile(Cout));
+}
+
+int tcs_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int ksize, float* packed, tcs_stream_t stream) {
+    const size_t n = tcs_conv_packed_floats(Cout, Cin, ksize);
+    if (!w_oihw || !packed || n == 0) return TCS_EINVAL;
+    hipLaunchKernelGGL(k_pack_weight, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tcs_stream(stream), w_oihw, Cout, Cin,
+                       ksize * ksize, round_up(Cin, 32), round_up(Cout, cout_tile(Cout)), packed);
+    return tcs_launch_status();
+}
+
+int tcs_conv2d(const tcs_conv_desc* d, tcs_stream_t stream) {
+    if (!d || !d->weight || !d->out) return TCS_EINVAL;
+    if (d->n_src < 1 || d->n_src > TCS_MAX_SRC) return TCS_EINVAL;
+    if (d->B <= 0 || d->B > 65535 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return TCS_EINVAL;
+    ConvArgs a;
+    int tot = 0;
+    for (int i = 0; i < TCS_MAX_SRC; ++i) {
+        const bool used = i < d->n_src;
+        if (used && (!d->src[i] || d->src_ch[i] <= 0)) return TCS_EINVAL;
+        a.src[i] = used ? d->src[i] : d->src[0];
+        a.src_ch[i] = used ? d->src_ch[i] : 1;
+        tot += used ? d->src_ch[i] : 0;
+        a.src_end[i] = used ? tot : 0x7fffffff;
+    }
+    if (tot != d->Cin) return TCS_EINVAL;
+    const int nt = cout_tile(d->Cout);
+    a.w = d->weight; a.bias = d->bias;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.CoutPad = round_up(d->Cout, nt);
+    a.act = d->act; a.post_scale = d->post_scale;
+    a.add1 = d->addend; a.add2 = d->addend2; a.h = d->h; a.z = d->z;
+    a.keep_z = d->blend_keep_z; a.hidden = 0;
+    a.out = d->out; a.out_ctot = d->out_ctot; a.out_coff = d->out_coff; a.out2 = d->out2;
+    a.npx = tcs_cdiv(d->W, 32);
+    a.npatch = a.npx * tcs_cdiv(d->H, 4);
+    a.nct = a.CoutPad / nt;
+    hipStream_t s = tcs_stream(stream);
+
+    if (d->epilogue == TCS_EPI_LINEAR) {
+        if (d->out_ctot < d->out_coff + d->Cout || d->out_coff < 0) return TCS_EINVAL;
+        if (d->Cin == 1) {
+            const dim3 grid(tcs_cdiv((long long)d->H * d->W, 256), d->B, tcs_cdiv(d->Cout, 16));
+            if (d->ksize == 1) hipLaunchKernelGGL(k_conv_cin1<1>, grid, dim3(256), 0, s, a);
+            else if (d->ksize == 3) hipLaunchKernelGGL(k_conv_cin1<3>, grid, dim3(256), 0, s, a);
+            else if (d->ksize == 7) hipLaunchKernelGGL(k_conv_cin1<7>, grid, dim3(256), 0, s, a);
+            else return TCS_EUNSUPPORTED;
+            return tcs_launch_status();
+        }
+        if (d->ksize == 3) return launch_by_tile<3, 8, TCS_EPI_LINEAR>(a, nt, s);
+        if (d->ksize == 1) return launch_by_tile<1, 32, TCS_EPI_LINEAR>(a, nt, s);
+        return TCS_EUNSUPPORTED;
+    }
+    // GRU epilogues: hidden = Cout/2 (ZR) or Cout (Q); tiles must not straddle the z|r boundary
+    if (!d->h) return TCS_EINVAL;
+    if (d->epilogue == TCS_EPI_GRU_ZR) {
+        if (!d->out2 || (d->Cout & 1)) return TCS_EINVAL;
+        a.hidden = d->Cout / 2;
+        if (d->ksize == 3) return launch_by_tile<3, 8, TCS_EPI_GRU_ZR>(a, nt, s);
+        if (d->ksize == 1) return launch_by_tile<1, 32, TCS_EPI_GRU_ZR>(a, nt, s);
+        return TCS_EUNSUPPORTED;
+    }
+    if (d->epilogue == TCS_EPI_GRU_Q) {
+        if (!d->z) return TCS_EINVAL;
+        a.hidden = d->Cout;
+        if (d->ksize == 3) return launch_by_tile<3, 8, TCS_EPI_GRU_Q>(a, nt, s);
+        if (d->ksize == 1) return launch_by_tile<1, 32, TCS_EPI_GRU_Q>(a, nt, s);
+        return TCS_EUNSUPPORTED;
+    }
+    return TCS_EINVAL;
+}
+
+}  // extern "C"

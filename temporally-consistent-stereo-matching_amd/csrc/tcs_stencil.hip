@@ -1,0 +1,236 @@
+// Small memory-bound stencils of the TC-Stereo refinement loop on gfx950.
+// Replaces the grouped-conv "one-hot kernel" formulations of the reference
+// (core/utils/geo_utils.py:73-132, core/update.py:259-300, core/tc_stereo.py:75-88) and the
+// avg_pool2d / interpolate glue of core/update.py:114-124 with direct stencil kernels.
+// One thread per output pixel; lanes run along x so every load/store is coalesced.
+#include "tcs_common.h"
+
+// tc_stereo.py:188-189
+__global__ __launch_bounds__(256) void k_flow_step(float* __restrict__ coords1, const float* __restrict__ delta, int W, int n,
+                                                   float* __restrict__ disp_q) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float c = coords1[i] + delta[i];
+    coords1[i] = c;
+    disp_q[i] = (float)(i % W) - c;
+}
+
+// geo_utils.py:115-132: replicate pad, forward differences
+__global__ __launch_bounds__(256) void k_grad_xy(const float* __restrict__ disp, int H, int W, float scale, float* __restrict__ grad) {
+    const int b = blockIdx.y, HW = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const int y = p / W, x = p - y * W;
+    const float* d = disp + (size_t)b * HW;
+    const float c = d[p];
+    const float r = d[y * W + min(x + 1, W - 1)];
+    const float dn = d[min(y + 1, H - 1) * W + x];
+    grad[((size_t)b * 2 + 0) * HW + p] = scale * (r - c);
+    grad[((size_t)b * 2 + 1) * HW + p] = scale * (dn - c);
+}
+
+// geo_utils.py:73-101 (level=2): 16 neighbour vectors (dilation 1 then 2, clockwise from top-left),
+// zero-padded disparity, cross product of vector k with vector (k+2) mod 16
+__global__ __launch_bounds__(256) void k_grad_candidates(const float* __restrict__ disp, int H, int W, float* __restrict__ out) {
+    const int b = blockIdx.y, HW = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const int y = p / W, x = p - y * W;
+    const float* d = disp + (size_t)b * HW;
+    const float c = d[p];
+    const int dv[8] = {-1, -1, -1, 0, 1, 1, 1, 0};
+    const int du[8] = {-1, 0, 1, 1, 1, 0, -1, -1};
+    float vx[16], vy[16], vz[16];
+#pragma unroll
+    for (int s = 1; s <= 2; ++s) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int yy = y + s * dv[k], xx = x + s * du[k];
+            const float nb = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? d[yy * W + xx] : 0.f;
+            const int i = (s - 1) * 8 + k;
+            vx[i] = (float)(s * du[k]);
+            vy[i] = (float)(s * dv[k]);
+            vz[i] = nb - c;
+        }
+    }
+    float* o = out + (size_t)b * 32 * HW + p;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int r = (k + 2) & 15;
+        const float nx = vy[k] * vz[r] - vz[k] * vy[r];
+        const float ny = vz[k] * vx[r] - vx[k] * vz[r];
+        const float nz = vx[k] * vy[r] - vy[k] * vx[r];
+        o[(size_t)k * HW] = -nx / nz;
+        o[(size_t)(16 + k) * HW] = -ny / nz;
+    }
+}
+
+// update.py:259-289
+__global__ __launch_bounds__(256) void k_propagate(const float* __restrict__ grad, const float* __restrict__ disp, int H, int W,
+                                                   float* __restrict__ out) {
+    const int b = blockIdx.y, HW = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const int y = p / W, x = p - y * W;
+    const float* d = disp + (size_t)b * HW;
+    const float* gx = grad + (size_t)b * 2 * HW;
+    const float* gy = gx + HW;
+    const float gcx = gx[p], gcy = gy[p];
+    float* o = out + (size_t)b * 27 * HW + p;
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int yy = y + v - 1, xx = x + u - 1;
+            const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const int q = min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1);
+            const float dn = d[q];                              // replicate pad
+            const float gnx = in ? gx[q] : 0.f;                 // zero pad
+            const float gny = in ? gy[q] : 0.f;
+            const int k = 3 * v + u;
+            o[(size_t)k * HW] = dn + gnx * (float)(1 - u) + gny * (float)(1 - v);
+            o[(size_t)(9 + k) * HW] = fabsf(gcx - gnx);
+            o[(size_t)(18 + k) * HW] = fabsf(gcy - gny);
+        }
+    }
+}
+
+// update.py:298-300 and tc_stereo.py:198-202
+__global__ __launch_bounds__(256) void k_softmax_blend(const float* __restrict__ logits, const float* __restrict__ cand, int cand_ctot,
+                                                       const float* __restrict__ disp_q, int W, int HW, float* __restrict__ refined,
+                                                       float* __restrict__ delta, float* __restrict__ coords1) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const float* l = logits + (size_t)b * 9 * HW + p;
+    const float* c = cand + (size_t)b * cand_ctot * HW + p;
+    float w[9], m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { w[k] = l[(size_t)k * HW]; m = fmaxf(m, w[k]); }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { w[k] = expf(w[k] - m); s += w[k]; }
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r += (w[k] / s) * c[(size_t)k * HW];
+    const size_t o = (size_t)b * HW + p;
+    refined[o] = r;
+    if (delta) delta[o] = r - disp_q[o];
+    if (coords1) coords1[o] = (float)(p % W) - r;
+}
+
+// tc_stereo.py:75-88 (factor 4) on flow = -disp, clipped like the returned dict (tc_stereo.py:223-224)
+__global__ __launch_bounds__(256) void k_convex_upsample(const float* __restrict__ disp, const float* __restrict__ mask, int H, int W,
+                                                         int clip, float* __restrict__ up, float* __restrict__ flow_q) {
+    const int b = blockIdx.y, HW = H * W;
+    const int Wu = 4 * W, Hu = 4 * H;
+    const int pu = blockIdx.x * 256 + threadIdx.x;
+    if (pu >= Hu * Wu) return;
+    const int yu = pu / Wu, xu = pu - yu * Wu;
+    const int y = yu >> 2, i = yu & 3, x = xu >> 2, j = xu & 3;
+    const float* d = disp + (size_t)b * HW;
+    const float* mk = mask + ((size_t)b * 144 + i * 4 + j) * HW + y * W + x;
+    float w[9], m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { w[k] = mk[(size_t)k * 16 * HW]; m = fmaxf(m, w[k]); }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { w[k] = expf(w[k] - m); s += w[k]; }
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+        const float f = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? 4.f * (-d[yy * W + xx]) : 0.f;
+        r += (w[k] / s) * f;
+    }
+    up[(size_t)b * Hu * Wu + pu] = clip ? fminf(r, 0.f) : r;
+    if (flow_q && i == 0 && j == 0) {
+        const float fq = -d[y * W + x];
+        flow_q[(size_t)b * HW + y * W + x] = clip ? fminf(fq, 0.f) : fq;
+    }
+}
+
+// update.py:114-115: 3x3 stride-2 pad-1 average, divisor always 9
+__global__ __launch_bounds__(256) void k_avgpool3s2(const float* __restrict__ x, int H, int W, int Ho, int Wo, float* __restrict__ out) {
+    const int bc = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= Ho * Wo) return;
+    const int yo = p / Wo, xo = p - yo * Wo;
+    const float* s = x + (size_t)bc * H * W;
+    float acc = 0.f;
+#pragma unroll
+    for (int v = -1; v <= 1; ++v) {
+#pragma unroll
+        for (int u = -1; u <= 1; ++u) {
+            const int yy = 2 * yo + v, xx = 2 * xo + u;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) acc += s[yy * W + xx];
+        }
+    }
+    out[(size_t)bc * Ho * Wo + p] = acc / 9.f;
+}
+
+extern "C" {
+
+int tcs_flow_step(float* coords1, const float* delta, int B, int H, int W, float* disp_q, tcs_stream_t stream) {
+    if (!coords1 || !delta || !disp_q || B <= 0 || H <= 0 || W <= 0) return TCS_EINVAL;
+    const int n = B * H * W;
+    hipLaunchKernelGGL(k_flow_step, dim3(tcs_cdiv(n, 256)), dim3(256), 0, tcs_stream(stream), coords1, delta, W, n, disp_q);
+    return tcs_launch_status();
+}
+
+int tcs_disp_gradient_xy(const float* disp, int B, int H, int W, float scale, float* grad, tcs_stream_t stream) {
+    if (!disp || !grad || B <= 0 || B > 65535 || H <= 0 || W <= 0) return TCS_EINVAL;
+    hipLaunchKernelGGL(k_grad_xy, dim3(tcs_cdiv((long long)H * W, 256), B), dim3(256), 0, tcs_stream(stream), disp, H, W, scale, grad);
+    return tcs_launch_status();
+}
+
+int tcs_grad_candidates(const float* disp, int B, int H, int W, float* cands, tcs_stream_t stream) {
+    if (!disp || !cands || B <= 0 || B > 65535 || H <= 0 || W <= 0) return TCS_EINVAL;
+    hipLaunchKernelGGL(k_grad_candidates, dim3(tcs_cdiv((long long)H * W, 256), B), dim3(256), 0, tcs_stream(stream), disp, H, W, cands);
+    return tcs_launch_status();
+}
+
+int tcs_propagate_disparity(const float* grad, const float* disp, int B, int H, int W, float* out27, tcs_stream_t stream) {
+    if (!grad || !disp || !out27 || B <= 0 || B > 65535 || H <= 0 || W <= 0) return TCS_EINVAL;
+    hipLaunchKernelGGL(k_propagate, dim3(tcs_cdiv((long long)H * W, 256), B), dim3(256), 0, tcs_stream(stream), grad, disp, H, W, out27);
+    return tcs_launch_status();
+}
+
+int tcs_softmax_blend(const float* logits9, const float* cand, int cand_ctot, const float* disp_q,
+                      int B, int H, int W, float* refined, float* delta_disp, float* coords1, tcs_stream_t stream) {
+    if (!logits9 || !cand || !refined || cand_ctot < 9 || B <= 0 || B > 65535 || H <= 0 || W <= 0) return TCS_EINVAL;
+    if (delta_disp && !disp_q) return TCS_EINVAL;
+    hipLaunchKernelGGL(k_softmax_blend, dim3(tcs_cdiv((long long)H * W, 256), B), dim3(256), 0, tcs_stream(stream),
+                       logits9, cand, cand_ctot, disp_q, W, H * W, refined, delta_disp, coords1);
+    return tcs_launch_status();
+}
+
+int tcs_convex_upsample(const float* disp, const float* mask, int B, int H, int W, int clip, float* flow_up, float* flow_q,
+                        tcs_stream_t stream) {
+    if (!disp || !mask || !flow_up || B <= 0 || B > 65535 || H <= 0 || W <= 0) return TCS_EINVAL;
+    hipLaunchKernelGGL(k_convex_upsample, dim3(tcs_cdiv((long long)16 * H * W, 256), B), dim3(256), 0, tcs_stream(stream),
+                       disp, mask, H, W, clip, flow_up, flow_q);
+    return tcs_launch_status();
+}
+
+int tcs_avgpool3s2(const float* x, int B, int C, int H, int W, float* out, tcs_stream_t stream) {
+    if (!x || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return TCS_EINVAL;
+    if ((long long)B * C > 65535) return TCS_EUNSUPPORTED;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    hipLaunchKernelGGL(k_avgpool3s2, dim3(tcs_cdiv((long long)Ho * Wo, 256), B * C), dim3(256), 0, tcs_stream(stream), x, H, W, Ho, Wo, out);
+    return tcs_launch_status();
+}
+
+int tcs_abi_version(void) { return 1; }
+
+const char* tcs_error_string(int code) {
+    switch (code) {
+        case TCS_OK: return "ok";
+        case TCS_EINVAL: return "invalid argument";
+        case TCS_ELAUNCH: return "HIP launch failed";
+        case TCS_EUNSUPPORTED: return "unsupported shape";
+        default: return "unknown error";
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,321 @@
+"""Tensor-level wrappers over the C ABI: validate, allocate outputs with torch, launch on the
+current HIP stream.  One function per operator of the reference's hot path (include/tcs_mi355.h
+cites the reference lines).  No arithmetic happens here."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import native as nv
+
+ACT = {"none": 0, "relu": 1, "sigmoid": 2, "tanh": 3, "leaky": 4}
+EPI_LINEAR, EPI_GRU_ZR, EPI_GRU_Q = 0, 1, 2
+
+
+def _new(like: torch.Tensor, *shape) -> torch.Tensor:
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def _dims4(t: torch.Tensor, name: str):
+    if t.ndim != 4:
+        raise ValueError(f"{name}: expected a 4-D NCHW tensor, got shape {tuple(t.shape)}")
+    return tuple(int(s) for s in t.shape)
+
+
+# ---------------------------------------------------------------------------------------------
+# correlation
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class CorrPyramid:
+    """Skewed 4-level pyramid in HBM (layout: include/tcs_mi355.h) plus what the build left behind."""
+    levels: List[torch.Tensor]
+    B: int
+    H: int
+    W: int
+    workspace: torch.Tensor                       # holds the natural-layout level 0 [B,H,W,W]
+    natural: Optional[List[torch.Tensor]] = None  # [B,H,W,W>>i], i = 0..3 (tests / API parity)
+    cost_volume: Optional[torch.Tensor] = None    # [B,W,H,W]
+    sparse: Optional[tuple] = None                # (disp, cost, mask), each [B,1,H,W]
+
+
+def corr_build(fmap1: torch.Tensor, fmap2: torch.Tensor, argmax: bool = False, cost_volume: bool = False,
+               natural: bool = False) -> CorrPyramid:
+    B, Cc, H, W = _dims4(fmap1, "fmap1")
+    if tuple(fmap2.shape) != (B, Cc, H, W):
+        raise ValueError(f"fmap2 shape {tuple(fmap2.shape)} != fmap1 shape {tuple(fmap1.shape)}")
+    L = nv.lib()
+    ws_bytes = L.tcs_corr_build_workspace_bytes(B, H, W)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=fmap1.device)
+    levels = [_new(fmap1, B, H, W >> i, W) for i in range(4)]
+    nat = [None] * 4
+    if natural:
+        nat = [None] + [_new(fmap1, B, H, W, W >> i) for i in range(1, 4)]
+    cost = _new(fmap1, B, W, H, W) if cost_volume else None
+    sp = tuple(_new(fmap1, B, 1, H, W) for _ in range(3)) if argmax else (None, None, None)
+    rc = L.tcs_corr_build(nv.ptr(fmap1, "fmap1"), nv.ptr(fmap2, "fmap2"), B, Cc, H, W,
+                          *[nv.ptr(t) for t in levels], nv.ptr(nat[1]), nv.ptr(nat[2]), nv.ptr(nat[3]), nv.ptr(cost),
+                          nv.ptr(sp[0]), nv.ptr(sp[1]), nv.ptr(sp[2]), nv.ptr(ws), nv.stream())
+    nv.check(rc, "tcs_corr_build")
+    out = CorrPyramid(levels, B, H, W, ws, cost_volume=cost, sparse=sp if argmax else None)
+    if natural:
+        out.natural = [ws[: B * H * W * W].view(B, H, W, W)] + nat[1:]
+    return out
+
+
+def corr_lookup(pyr: CorrPyramid, coords: torch.Tensor, radius: int = 4, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if tuple(coords.shape) != (pyr.B, 1, pyr.H, pyr.W):
+        raise ValueError(f"coords shape {tuple(coords.shape)} != {(pyr.B, 1, pyr.H, pyr.W)}")
+    n_ch = 4 * (2 * radius + 1)
+    if out is None:
+        out = _new(coords, pyr.B, n_ch, pyr.H, pyr.W)
+    elif tuple(out.shape) != (pyr.B, n_ch, pyr.H, pyr.W):
+        raise ValueError("corr_lookup: bad `out` shape")
+    rc = nv.lib().tcs_corr_lookup(*[nv.ptr(t) for t in pyr.levels], nv.ptr(coords, "coords"), pyr.B, pyr.H, pyr.W, radius,
+                                  nv.ptr(out, "out"), nv.stream())
+    nv.check(rc, "tcs_corr_lookup")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# temporal warp
+# ---------------------------------------------------------------------------------------------
+def _cam(T_rel, K, K_inv, baseline, B):
+    T_rel = T_rel.reshape(B, 4, 4).float().contiguous()
+    K = K.reshape(B, 3, 3).float().contiguous()
+    K_inv = K_inv.reshape(B, 3, 3).float().contiguous()
+    baseline = baseline.reshape(-1).float().contiguous()
+    if baseline.numel() != B:
+        raise ValueError(f"baseline has {baseline.numel()} entries for batch {B}")
+    return T_rel, K, K_inv, baseline
+
+
+def warp_forward(prev_disp, prev_fmap, T_rel, K, K_inv, baseline, cur_fmap=None, want_fmap=True):
+    """-> (disp [B,1,H,W], fmap [B,C,H,W] or None, mask [B,1,H,W], cost [B,1,H,W] or None)"""
+    B, Cc, H, W = _dims4(prev_fmap, "prev_fmap")
+    if tuple(prev_disp.shape) != (B, 1, H, W):
+        raise ValueError("prev_disp must be [B,1,H,W] matching prev_fmap")
+    T_rel, K, K_inv, baseline = _cam(T_rel, K, K_inv, baseline, B)
+    L = nv.lib()
+    ws = torch.empty(L.tcs_warp_workspace_bytes(B, Cc, H, W) // 4, dtype=torch.float32, device=prev_fmap.device)
+    o_disp, o_mask = _new(prev_disp, B, 1, H, W), _new(prev_disp, B, 1, H, W)
+    o_fmap = _new(prev_fmap, B, Cc, H, W) if want_fmap else None
+    o_cost = _new(prev_disp, B, 1, H, W) if cur_fmap is not None else None
+    rc = L.tcs_warp_forward(nv.ptr(prev_disp, "prev_disp"), nv.ptr(prev_fmap, "prev_fmap"), nv.ptr(T_rel), nv.ptr(K), nv.ptr(K_inv),
+                            nv.ptr(baseline), B, Cc, H, W, nv.ptr(o_disp), nv.ptr(o_fmap), nv.ptr(o_mask),
+                            nv.ptr(cur_fmap, "cur_fmap"), nv.ptr(o_cost), nv.ptr(ws), nv.stream())
+    nv.check(rc, "tcs_warp_forward")
+    return o_disp, o_fmap, o_mask, o_cost
+
+
+def warp_geometry(prev_disp, T_rel, K, K_inv, baseline):
+    B, _, H, W = _dims4(prev_disp, "prev_disp")
+    T_rel, K, K_inv, baseline = _cam(T_rel, K, K_inv, baseline, B)
+    L = nv.lib()
+    ws = torch.empty(L.tcs_warp_workspace_bytes(B, 0, H, W) // 4, dtype=torch.float32, device=prev_disp.device)
+    cd, va, me = (_new(prev_disp, B, 1, H, W) for _ in range(3))
+    fl = _new(prev_disp, B, 2, H, W)
+    rc = L.tcs_warp_geometry(nv.ptr(prev_disp, "prev_disp"), nv.ptr(T_rel), nv.ptr(K), nv.ptr(K_inv), nv.ptr(baseline), B, H, W,
+                             nv.ptr(cd), nv.ptr(va), nv.ptr(fl), nv.ptr(me), nv.ptr(ws), nv.stream())
+    nv.check(rc, "tcs_warp_geometry")
+    return cd, va, fl, me
+
+
+def softsplat_sum(inp, flow):
+    B, Cc, H, W = _dims4(inp, "tenIn")
+    if tuple(flow.shape) != (B, 2, H, W):
+        raise ValueError("tenFlow must be [B,2,H,W]")
+    out = torch.zeros_like(inp)
+    nv.check(nv.lib().tcs_softsplat_sum(nv.ptr(inp, "tenIn"), nv.ptr(flow, "tenFlow"), B, Cc, H, W, nv.ptr(out), nv.stream()),
+             "tcs_softsplat_sum")
+    return out
+
+
+def backward_grid(disp, T_rel, K, K_inv, baseline):
+    B, _, H, W = _dims4(disp, "disp")
+    T_rel, K, K_inv, baseline = _cam(T_rel, K, K_inv, baseline, B)
+    grid = _new(disp, B, 2, H, W)
+    nv.check(nv.lib().tcs_backward_grid(nv.ptr(disp, "disp"), nv.ptr(T_rel), nv.ptr(K), nv.ptr(K_inv), nv.ptr(baseline), B, H, W,
+                                        nv.ptr(grid), nv.stream()), "tcs_backward_grid")
+    return grid
+
+
+def bilinear_sample(img, grid):
+    B, Cc, Hi, Wi = _dims4(img, "img")
+    Bg, two, Ho, Wo = _dims4(grid, "grid")
+    if Bg != B or two != 2:
+        raise ValueError("grid must be [B,2,Ho,Wo]")
+    out = _new(img, B, Cc, Ho, Wo)
+    nv.check(nv.lib().tcs_bilinear_sample(nv.ptr(img, "img"), nv.ptr(grid, "grid"), B, Cc, Hi, Wi, Ho, Wo, nv.ptr(out), nv.stream()),
+             "tcs_bilinear_sample")
+    return out
+
+
+def grid_halve(grid):
+    B, _, H, W = _dims4(grid, "grid")
+    out = _new(grid, B, 2, H // 2, W // 2)
+    nv.check(nv.lib().tcs_grid_halve(nv.ptr(grid, "grid"), B, H, W, nv.ptr(out), nv.stream()), "tcs_grid_halve")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# stencils
+# ---------------------------------------------------------------------------------------------
+def flow_step(coords1, delta, disp_q=None):
+    B, _, H, W = _dims4(coords1, "coords1")
+    if disp_q is None:
+        disp_q = torch.empty_like(coords1)
+    nv.check(nv.lib().tcs_flow_step(nv.ptr(coords1, "coords1"), nv.ptr(delta, "delta"), B, H, W, nv.ptr(disp_q), nv.stream()),
+             "tcs_flow_step")
+    return disp_q
+
+
+def disp_gradient_xy(disp, scale: float = 1.0, out=None):
+    B, _, H, W = _dims4(disp, "disp")
+    out = _new(disp, B, 2, H, W) if out is None else out
+    nv.check(nv.lib().tcs_disp_gradient_xy(nv.ptr(disp, "disp"), B, H, W, float(scale), nv.ptr(out), nv.stream()), "tcs_disp_gradient_xy")
+    return out
+
+
+def grad_candidates(disp, out=None):
+    B, _, H, W = _dims4(disp, "disp")
+    out = _new(disp, B, 32, H, W) if out is None else out
+    nv.check(nv.lib().tcs_grad_candidates(nv.ptr(disp, "disp"), B, H, W, nv.ptr(out), nv.stream()), "tcs_grad_candidates")
+    return out
+
+
+def propagate_disparity(grad, disp, out=None):
+    B, _, H, W = _dims4(disp, "disp")
+    out = _new(disp, B, 27, H, W) if out is None else out
+    nv.check(nv.lib().tcs_propagate_disparity(nv.ptr(grad, "grad"), nv.ptr(disp, "disp"), B, H, W, nv.ptr(out), nv.stream()),
+             "tcs_propagate_disparity")
+    return out
+
+
+def softmax_blend(logits9, cand, disp_q=None, want_delta=False, coords1=None, refined=None):
+    B, _, H, W = _dims4(logits9, "logits")
+    refined = _new(logits9, B, 1, H, W) if refined is None else refined
+    delta = _new(logits9, B, 1, H, W) if want_delta else None
+    nv.check(nv.lib().tcs_softmax_blend(nv.ptr(logits9, "logits"), nv.ptr(cand, "cand"), int(cand.shape[1]), nv.ptr(disp_q), B, H, W,
+                                        nv.ptr(refined), nv.ptr(delta), nv.ptr(coords1), nv.stream()), "tcs_softmax_blend")
+    return refined, delta
+
+
+def convex_upsample(disp, mask, clip=True):
+    B, _, H, W = _dims4(disp, "disp")
+    if tuple(mask.shape) != (B, 144, H, W):
+        raise ValueError("mask must be [B,144,H,W] (factor 4)")
+    up, fq = _new(disp, B, 1, 4 * H, 4 * W), _new(disp, B, 1, H, W)
+    nv.check(nv.lib().tcs_convex_upsample(nv.ptr(disp, "disp"), nv.ptr(mask, "mask"), B, H, W, int(clip), nv.ptr(up), nv.ptr(fq), nv.stream()),
+             "tcs_convex_upsample")
+    return up, fq
+
+
+def avgpool3s2(x, out=None):
+    B, Cc, H, W = _dims4(x, "x")
+    out = _new(x, B, Cc, (H - 1) // 2 + 1, (W - 1) // 2 + 1) if out is None else out
+    nv.check(nv.lib().tcs_avgpool3s2(nv.ptr(x, "x"), B, Cc, H, W, nv.ptr(out), nv.stream()), "tcs_avgpool3s2")
+    return out
+
+
+def resize_bilinear(x, Ho: int, Wo: int, out=None):
+    B, Cc, H, W = _dims4(x, "x")
+    out = _new(x, B, Cc, Ho, Wo) if out is None else out
+    nv.check(nv.lib().tcs_resize_bilinear(nv.ptr(x, "x"), B, Cc, H, W, Ho, Wo, nv.ptr(out), nv.stream()), "tcs_resize_bilinear")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# convolutions on the matrix cores
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class PackedConv:
+    weight: torch.Tensor           # kernel layout (tcs_pack_conv_weight)
+    bias: Optional[torch.Tensor]
+    cout: int
+    cin: int
+    ksize: int
+
+
+def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> PackedConv:
+    cout, cin, kh, kw = (int(s) for s in weight.shape)
+    if kh != kw:
+        raise ValueError("square kernels only")
+    L = nv.lib()
+    n = L.tcs_conv_packed_floats(cout, cin, kh)
+    if n == 0:
+        raise ValueError(f"unsupported convolution [{cout},{cin},{kh},{kw}]")
+    w = weight.detach().float().contiguous()
+    packed = torch.empty(n, dtype=torch.float32, device=w.device)
+    nv.check(L.tcs_pack_conv_weight(nv.ptr(w, "weight"), cout, cin, kh, nv.ptr(packed), nv.stream()), "tcs_pack_conv_weight")
+    b = None if bias is None else bias.detach().float().contiguous()
+    return PackedConv(packed, b, cout, cin, kh)
+
+
+def _desc(pc: PackedConv, srcs: Sequence[torch.Tensor]) -> nv.ConvDesc:
+    if not 1 <= len(srcs) <= 4:
+        raise ValueError("1..4 sources")
+    B, _, H, W = _dims4(srcs[0], "src0")
+    d = nv.ConvDesc()
+    tot = 0
+    for i, s in enumerate(srcs):
+        bs, cs, hs, ws_ = _dims4(s, f"src{i}")
+        if (bs, hs, ws_) != (B, H, W):
+            raise ValueError(f"src{i} shape {tuple(s.shape)} does not match src0 {tuple(srcs[0].shape)}")
+        d.src[i] = nv.ptr(s, f"src{i}")
+        d.src_ch[i] = cs
+        tot += cs
+    if tot != pc.cin:
+        raise ValueError(f"sources carry {tot} channels, convolution expects {pc.cin}")
+    d.n_src = len(srcs)
+    d.weight = nv.ptr(pc.weight)
+    d.bias = nv.ptr(pc.bias)
+    d.B, d.H, d.W, d.Cin, d.Cout, d.ksize = B, H, W, pc.cin, pc.cout, pc.ksize
+    d.post_scale = 1.0
+    return d
+
+
+def conv2d(pc: PackedConv, srcs: Sequence[torch.Tensor], act: str = "none", addend=None, post_scale: float = 1.0,
+           out: Optional[torch.Tensor] = None, out_coff: int = 0) -> torch.Tensor:
+    d = _desc(pc, srcs)
+    if out is None:
+        out = _new(srcs[0], d.B, pc.cout, d.H, d.W)
+    if out.shape[0] != d.B or tuple(out.shape[2:]) != (d.H, d.W):
+        raise ValueError("conv2d: bad `out` shape")
+    if addend is not None and tuple(addend.shape) != (d.B, pc.cout, d.H, d.W):
+        raise ValueError("conv2d: bad addend shape")
+    d.epilogue, d.act, d.post_scale = EPI_LINEAR, ACT[act], float(post_scale)
+    d.addend = nv.ptr(addend, "addend")
+    d.out, d.out_ctot, d.out_coff = nv.ptr(out, "out"), int(out.shape[1]), int(out_coff)
+    nv.check(nv.lib().tcs_conv2d(C.byref(d), nv.stream()), "tcs_conv2d")
+    return out
+
+
+def gru_gates(pc_zr: PackedConv, srcs, h, cz=None, cr=None, z_out=None, rh_out=None):
+    """z = sigmoid(conv_zr[:hid] + cz), rh = sigmoid(conv_zr[hid:] + cr) * h   (update.py:81-83, 30-33)."""
+    d = _desc(pc_zr, srcs)
+    hid = pc_zr.cout // 2
+    if tuple(h.shape) != (d.B, hid, d.H, d.W):
+        raise ValueError("gru_gates: bad h shape")
+    z_out = torch.empty_like(h) if z_out is None else z_out
+    rh_out = torch.empty_like(h) if rh_out is None else rh_out
+    d.epilogue = EPI_GRU_ZR
+    d.addend, d.addend2, d.h = nv.ptr(cz, "cz"), nv.ptr(cr, "cr"), nv.ptr(h, "h")
+    d.out, d.out2, d.out_ctot, d.out_coff = nv.ptr(z_out, "z"), nv.ptr(rh_out, "rh"), hid, 0
+    nv.check(nv.lib().tcs_conv2d(C.byref(d), nv.stream()), "tcs_conv2d[gru_zr]")
+    return z_out, rh_out
+
+
+def gru_update(pc_q: PackedConv, srcs, h, z, cq=None, keep_z: bool = False, out=None):
+    """q = tanh(conv_q + cq); h' = (1-z)h + zq (keep_z=False, update.py:85) or zh + (1-z)q (update.py:34,66)."""
+    d = _desc(pc_q, srcs)
+    if tuple(h.shape) != (d.B, pc_q.cout, d.H, d.W) or z.shape != h.shape:
+        raise ValueError("gru_update: bad h/z shape")
+    out = torch.empty_like(h) if out is None else out
+    d.epilogue = EPI_GRU_Q
+    d.addend, d.h, d.z, d.blend_keep_z = nv.ptr(cq, "cq"), nv.ptr(h, "h"), nv.ptr(z, "z"), int(keep_z)
+    d.out, d.out_ctot, d.out_coff = nv.ptr(out, "out"), pc_q.cout, 0
+    nv.check(nv.lib().tcs_conv2d(C.byref(d), nv.stream()), "tcs_conv2d[gru_q]")
+    return out

@@ -1,0 +1,308 @@
+"""GPU parity: the HIP path (through the C ABI) against reference-generated goldens and the CPU
+oracle on identical inputs.  Tolerances are SURVEY.md §8c's: per-op <= 1e-5 abs for lookup / build /
+stencils, <= 1e-4 for conv stacks, end-to-end EPE <= 1e-4 (8 iters) and <= 1e-3 (32 iters)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import T, epe, maxdiff
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from tcs_mi355 import native
+    native.lib()                                   # fail loudly when the HIP library is missing
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def model(dev, synth_weights):
+    from argparse import Namespace
+    from core.tc_stereo import TCStereo
+    args = Namespace(hidden_dims=[128] * 3, shared_backbone=True, corr_levels=4, corr_radius=4, n_downsample=2,
+                     context_norm="none", slow_fast_gru=False, n_gru_layers=3, mixed_precision=False, init_thres=0.5)
+    m = TCStereo(args)
+    m.load_state_dict(synth_weights, strict=True)
+    return m.to(dev).eval()
+
+
+def D(x, dev):
+    return (x if torch.is_tensor(x) else T(x)).to(dev).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# correlation
+# ------------------------------------------------------------------------------------------------
+def test_corr_build_golden(dev, ops_golden):
+    from tcs_mi355 import ops
+    g = ops_golden
+    for tag in "ab":
+        p = ops.corr_build(D(g[f"corr{tag}_f1"], dev), D(g[f"corr{tag}_f2"], dev), argmax=True, cost_volume=True, natural=True)
+        for i in range(4):
+            assert maxdiff(p.natural[i], g[f"corr{tag}_pyr{i}"]) <= 1e-5, (tag, i)
+        assert maxdiff(p.cost_volume, g[f"corr{tag}_cost"]) <= 1e-5
+        d, c, m = p.sparse
+        assert maxdiff(m, g[f"corr{tag}_sparse_mask"]) == 0
+        assert maxdiff(d, g[f"corr{tag}_sparse_disp"]) == 0
+        assert maxdiff(c, g[f"corr{tag}_sparse_cost"]) <= 1e-5
+
+
+def test_corr_lookup_golden(dev, ops_golden):
+    from tcs_mi355 import ops
+    g = ops_golden
+    for tag in "ab":
+        p = ops.corr_build(D(g[f"corr{tag}_f1"], dev), D(g[f"corr{tag}_f2"], dev))
+        out = ops.corr_lookup(p, D(g[f"corr{tag}_coords"], dev), 4)
+        assert maxdiff(out, g[f"corr{tag}_lookup"]) <= 1e-5, tag
+
+
+@pytest.mark.parametrize("shape", [(1, 256, 120, 160), (1, 256, 96, 312), (2, 32, 5, 19)])
+def test_corr_full_size_vs_oracle(dev, oracle, shape):
+    """C2 (120x160) and C5 (96x312) grid sizes + a ragged one; lookup with radius 4 and a generic radius."""
+    from tcs_mi355 import ops
+    B, Cc, H, W = shape
+    gen = torch.Generator().manual_seed(H * W)
+    f1, f2 = torch.randn(shape, generator=gen), torch.randn(shape, generator=gen)
+    f2[..., 5:] = 0.5 * f2[..., 5:] + 0.5 * f1[..., :-5]
+    p = ops.corr_build(D(f1, dev), D(f2, dev), argmax=True, natural=True)
+    vol = oracle.corr_volume(f1, f2)
+    pyr = oracle.corr_pyramid(vol)
+    for i in range(4):
+        assert maxdiff(p.natural[i], pyr[i]) <= 1e-5
+    sd, sc, sm = oracle.argmax_disp(oracle.masked_cost_volume(vol))
+    # argmax can legitimately flip on a near-tie of two fp32 sums; demand agreement on >= 99.9 % of pixels
+    agree = (p.sparse[2].cpu() == sm).float().mean().item()
+    assert agree >= 0.999
+    same = (p.sparse[2].cpu() == sm) & (p.sparse[0].cpu() == sd)
+    assert same.float().mean().item() >= 0.999
+    xs = torch.arange(W, dtype=torch.float32).view(1, 1, 1, W).expand(B, 1, H, W)
+    coords = (xs - torch.rand(B, 1, H, W, generator=gen) * 40 + 4).contiguous()
+    got = ops.corr_lookup(p, D(coords, dev), 4)
+    assert maxdiff(got, oracle.corr_lookup(pyr, coords, 4)) <= 1e-5
+    got3 = ops.corr_lookup(p, D(coords, dev), 3)
+    assert maxdiff(got3, oracle.corr_lookup(pyr, coords, 3)) <= 1e-5
+
+
+def test_corr_lookup_integer_coords_property(dev):
+    """Size-independent property at full C2 size: at integer coordinates the centre tap of level 0
+    is exactly V[b,h,w1,x] and out-of-range taps are exactly 0."""
+    from tcs_mi355 import ops
+    B, Cc, H, W = 1, 256, 120, 160
+    gen = torch.Generator().manual_seed(3)
+    f1, f2 = torch.randn(B, Cc, H, W, generator=gen).to(dev), torch.randn(B, Cc, H, W, generator=gen).to(dev)
+    p = ops.corr_build(f1, f2, natural=True)
+    xi = torch.randint(-8, W + 8, (B, 1, H, W), generator=gen)
+    out = ops.corr_lookup(p, xi.float().to(dev), 4)
+    vol = p.natural[0]
+    inside = (xi >= 0) & (xi < W)
+    want = torch.gather(vol, 3, xi.clamp(0, W - 1).to(dev).permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+    centre = out[:, 4:5]
+    assert torch.equal(centre[inside.to(dev)], want[inside.to(dev)])
+    assert (centre[~inside.to(dev)] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# temporal warp
+# ------------------------------------------------------------------------------------------------
+def test_warp_geometry_and_grid_golden(dev, ops_golden):
+    from tcs_mi355 import ops
+    g = ops_golden
+    d, K, Ki, Tr, b = (D(g[k], dev) for k in ("geo_disp", "geo_K", "geo_Kinv", "geo_Trel", "geo_baseline"))
+    cd, va, fl, me = ops.warp_geometry(d, Tr, K, Ki, b)
+    assert maxdiff(cd, g["geo_warp_disp"]) <= 1e-4
+    assert maxdiff(va, g["geo_warp_valid"]) == 0
+    assert maxdiff(fl, g["geo_warp_flow"]) <= 2e-4
+    assert maxdiff(me, g["geo_warp_metric"]) <= 1e-4
+    assert maxdiff(ops.backward_grid(d, Tr, K, Ki, b), g["geo_backward_grid"]) <= 2e-4
+    assert maxdiff(ops.bilinear_sample(D(g["samp_img"], dev), D(g["samp_grid"], dev)), g["samp_out"]) <= 1e-5
+
+
+def test_warp_forward_golden_and_api(dev, ops_golden):
+    """warp() via the fused kernels vs the reference wrapper run through the stand-in splat
+    (restatement-pinned), and the drop-in softsplat() wrapper vs the same numbers."""
+    from core.utils.geo_utils import warp
+    g = ops_golden
+    d, K, Ki, Tr, b = (D(g[k], dev) for k in ("geo_disp", "geo_K", "geo_Kinv", "geo_Trel", "geo_baseline"))
+    wd, wf, wm = warp(d, D(g["rp_warp_fmap_in"], dev), Tr, K, Ki, b)
+    assert maxdiff(wm, g["rp_warp_mask"]) == 0
+    assert maxdiff(wd, g["rp_warp_disp"]) <= 1e-4
+    assert maxdiff(wf, g["rp_warp_fmap"]) <= 1e-4
+
+
+def test_softsplat_vs_oracle(dev, oracle):
+    from core.utils.splatting.softsplat import softsplat
+    from tcs_mi355 import ops
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 7, 33, 45, generator=gen)
+    flow = torch.randn(2, 2, 33, 45, generator=gen) * 3
+    flow[0, 0, 0, 0] = float("nan")
+    flow[1, 1, 2, 3] = 1e30
+    flow[0, :, 5, 5] = torch.tensor([-100.0, 0.3])
+    got = ops.softsplat_sum(D(x, dev), D(flow, dev))
+    assert maxdiff(got, oracle.softsplat_forward(x, flow)) <= 1e-5
+    metric = torch.randn(2, 1, 33, 45, generator=gen)
+    valid = (torch.rand(2, 1, 33, 45, generator=gen) > 0.2).float()
+    out, mask = softsplat(D(x, dev), D(flow, dev), D(metric, dev), "soft-clipeps", D(valid, dev))
+    e = metric.exp()
+    ref = oracle.softsplat_forward(torch.cat([x * valid * e, e * valid], 1), flow)
+    assert maxdiff(mask, (ref[:, -1:] != 0).float()) == 0
+    assert maxdiff(out, ref[:, :-1] / ref[:, -1:].clamp_min(1e-7)) <= 1e-4
+
+
+def test_warp_full_size_vs_oracle(dev, oracle):
+    """C2 grid (120x160, 256 channels): fused warp + cost vs the oracle."""
+    from tcs_mi355 import ops
+    gen = torch.Generator().manual_seed(5)
+    B, Cc, H, W = 1, 256, 120, 160
+    disp = torch.rand(B, 1, H, W, generator=gen) * 30 + 1
+    disp[:, :, :, 80:] += 15                                  # a depth discontinuity
+    fm, cur = torch.randn(B, Cc, H, W, generator=gen), torch.randn(B, Cc, H, W, generator=gen)
+    K = torch.tensor([[[80.0, 0, 80.0], [0, 80.0, 60.0], [0, 0, 1.0]]])
+    Ki = torch.linalg.inv(K)
+    Tr = torch.eye(4)[None].clone()
+    Tr[0, :3, 3] = torch.tensor([0.03, -0.01, -0.06])
+    Tr[0, :3, :3] = torch.tensor([[0.9998, 0, 0.02], [0, 1, 0], [-0.02, 0, 0.9998]])
+    b = torch.tensor([0.25])
+    wd, wf, wm, wc = ops.warp_forward(D(disp, dev), D(fm, dev), D(Tr, dev), D(K, dev), D(Ki, dev), D(b, dev), cur_fmap=D(cur, dev))
+    od, of, om = oracle.forward_warp(disp, fm, Tr, K, Ki, b)
+    oc = (F.normalize(cur, dim=1) * F.normalize(of, dim=1)).sum(1, keepdim=True) * om
+    assert maxdiff(wm, om) == 0
+    assert maxdiff(wd, od) <= 2e-4
+    assert maxdiff(wf, of) <= 2e-4
+    assert maxdiff(wc, oc) <= 1e-5
+    grid = ops.backward_grid(D(disp, dev), D(Tr, dev), D(K, dev), D(Ki, dev), D(b, dev))
+    assert maxdiff(grid, oracle.backward_grid(disp, Tr, K, Ki, b)) <= 2e-4
+    nets = [torch.randn(1, 128, H >> i, W >> i, generator=gen) for i in range(3)]
+    want = oracle.warp_hidden_states(nets, grid.cpu())
+    gcur = grid
+    for i in range(3):
+        assert maxdiff(ops.bilinear_sample(D(nets[i], dev), gcur), want[i]) <= 1e-5
+        if i < 2:
+            gcur = ops.grid_halve(gcur)
+
+
+# ------------------------------------------------------------------------------------------------
+# stencils
+# ------------------------------------------------------------------------------------------------
+def test_stencils_golden(dev, ops_golden, model):
+    from core.utils.geo_utils import disp2disp_grad_candidates, disp2disp_gradient_xy
+    from tcs_mi355 import ops
+    g = ops_golden
+    d = D(g["geo_disp"], dev)
+    assert maxdiff(disp2disp_gradient_xy(d)[0], g["geo_grad_xy"]) == 0
+    ref = g["geo_grad_cands"]
+    got = disp2disp_grad_candidates(d, level=2).cpu().numpy()
+    fin = np.isfinite(ref)
+    assert (np.isfinite(got) == fin).all()
+    assert np.abs(got[fin] - ref[fin]).max() <= 1e-5 * max(1.0, np.abs(ref[fin]).max())
+    cand, mat = model.disp_refine.propagate_disparity(D(g["prop_grad"], dev), D(g["prop_disp"], dev))
+    assert maxdiff(cand, g["prop_cand"]) <= 1e-6
+    assert maxdiff(mat, g["prop_matrix"]) == 0
+    assert maxdiff(model.upsample_flow(D(g["ups_flow"], dev), D(g["ups_mask"], dev)), g["ups_out"]) <= 2e-6
+    x = torch.randn(2, 6, 13, 17)
+    assert maxdiff(ops.avgpool3s2(D(x, dev)), F.avg_pool2d(x, 3, stride=2, padding=1)) <= 1e-6
+    assert maxdiff(ops.resize_bilinear(D(x, dev), 26, 34), F.interpolate(x, (26, 34), mode="bilinear", align_corners=True)) <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# MFMA convolutions and the blocks built from them
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [
+    dict(B=1, cins=(128, 128, 128), cout=256, k=3, H=12, W=40),       # gru08-like, 3 virtual sources
+    dict(B=2, cins=(36,), cout=64, k=1, H=9, W=37),                    # convc1-like, ragged size, batch 2
+    dict(B=1, cins=(64, 64), cout=127, k=3, H=8, W=24),                # encoder.conv: 127 outputs
+    dict(B=1, cins=(1,), cout=64, k=7, H=10, W=33),                    # convf1: single input channel
+    dict(B=1, cins=(27,), cout=96, k=1, H=7, W=65),                    # disp_f_stem: 27 inputs
+    dict(B=1, cins=(256,), cout=1, k=3, H=6, W=32),                    # flow head conv2
+    dict(B=1, cins=(128,), cout=384, k=3, H=30, W=40),                 # context_zqr conv: 3 cout tiles
+])
+def test_conv2d_vs_torch(dev, cfg):
+    from tcs_mi355 import ops
+    gen = torch.Generator().manual_seed(cfg["cout"] + cfg["k"])
+    cin = sum(cfg["cins"])
+    w = torch.randn(cfg["cout"], cin, cfg["k"], cfg["k"], generator=gen) * (2.0 / (cin * cfg["k"] ** 2)) ** 0.5
+    b = torch.randn(cfg["cout"], generator=gen) * 0.1
+    xs = [torch.randn(cfg["B"], c, cfg["H"], cfg["W"], generator=gen) for c in cfg["cins"]]
+    add = torch.randn(cfg["B"], cfg["cout"], cfg["H"], cfg["W"], generator=gen)
+    ref = F.conv2d(torch.cat(xs, 1).double(), w.double(), b.double(), padding=cfg["k"] // 2)
+    pc = ops.pack_conv(D(w, dev), D(b, dev))
+    got = ops.conv2d(pc, [D(x, dev) for x in xs])
+    assert maxdiff(got, ref) <= 2e-5
+    got = ops.conv2d(pc, [D(x, dev) for x in xs], act="relu", addend=D(add, dev), post_scale=0.25)
+    assert maxdiff(got, 0.25 * torch.relu(ref + add.double())) <= 2e-5
+    for act, fn in (("sigmoid", torch.sigmoid), ("tanh", torch.tanh), ("leaky", lambda t: F.leaky_relu(t, 0.01))):
+        assert maxdiff(ops.conv2d(pc, [D(x, dev) for x in xs], act=act), fn(ref)) <= 2e-5
+
+
+def test_cells_and_blocks_golden(dev, ops_golden, model):
+    g = ops_golden
+    net = [D(g["ub_h08"], dev), D(g["ub_h16"], dev), D(g["ub_h32"], dev)]
+    inp = [[D(g[f"ub_ctx{i}{n}"], dev) for n in "zrq"] for i in range(3)]
+    out, delta = model.update_block(net, inp, D(g["ub_corr"], dev), D(g["ub_flow"], dev))
+    assert maxdiff(delta, g["ub_delta"]) <= 1e-4
+    for o, k in zip(out, ("ub_out08", "ub_out16", "ub_out32")):
+        assert maxdiff(o, g[k]) <= 1e-4, k
+    assert maxdiff(model.update_block.encoder(D(g["ub_flow"], dev), D(g["ub_corr"], dev)), g["enc_out"]) <= 1e-4
+    assert maxdiff(model.previous_current_hideen_fuse[0](D(g["ub_h08"], dev), D(g["lf_x"], dev)), g["lf_out"]) <= 1e-5
+    assert maxdiff(model.hiddenstate_update(D(g["ub_h08"], dev), D(g["hu_delta"], dev)), g["hu_out"]) <= 1e-5
+    grad, ctx = model.disp_grad_refine(D(g["prop_grad"], dev), D(g["prop_disp"], dev), [D(g[f"dg_ctx{i}"], dev) for i in range(3)])
+    assert maxdiff(grad, g["dg_grad"]) <= 1e-4
+    assert maxdiff(ctx, g["dg_context"]) <= 1e-4
+    ref, mask = model.disp_refine(D(g["prop_grad"], dev), D(g["prop_disp"], dev), D(g["ub_h08"], dev), D(g["dg_context"], dev), False)
+    assert maxdiff(ref, g["dr_refined"]) <= 1e-4
+    assert maxdiff(mask, g["dr_mask"]) <= 1e-4
+    ref2, none = model.disp_refine(D(g["prop_grad"], dev), D(g["prop_disp"], dev), D(g["ub_h08"], dev), D(g["dg_context"], dev), True)
+    assert none is None and maxdiff(ref2, ref) == 0
+    comp, mono, w, nets = model.disp_completor(D(g["dc_disp"], dev), D(g["dc_cost"], dev), D(g["dc_mask"], dev),
+                                               [D(g[f"dc_net{i}"], dev) for i in range(3)])
+    assert maxdiff(comp, g["dc_completed"]) <= 1e-4
+    for i in range(3):
+        assert maxdiff(nets[i], g[f"dc_out{i}"]) <= 2e-4
+
+
+# ------------------------------------------------------------------------------------------------
+# end to end
+# ------------------------------------------------------------------------------------------------
+def test_e2e_c1_golden(dev, e2e_golden, model):
+    """BASELINE config 1: 320x240, D=64, 8 iters, first frame, vs the reference's own output."""
+    from tcs_mi355 import synth
+    from tcs_mi355.harness import InputPadder
+    pr = synth.make_pair(1)
+    i1, i2 = D(pr.image1, dev)[None], D(pr.image2, dev)[None]
+    (p1, p2), _ = InputPadder(i1.shape, divis_by=32).pad(i1, i2)
+    out = model(p1, p2, iters=8, test_mode=True)
+    assert tuple(out["flow"].shape) == (1, 1, 256, 320)
+    assert epe(out["flow_q"], e2e_golden["c1_flow_q"]) <= 1e-4
+    assert epe(out["flow"], e2e_golden["c1_flow"]) <= 1e-4
+    assert maxdiff(out["fmap1"].sum((2, 3)), e2e_golden["c1_fmap1_sum"]) <= 1e-2
+    assert float(out["flow"].max()) <= 0.0
+
+
+def test_e2e_temporal_clip_golden(dev, e2e_golden, model):
+    """3-frame clip through the evaluation harness: argmax branch then two warp-branch frames."""
+    from tcs_mi355 import synth
+    from tcs_mi355.harness import run_sequence
+    seq = synth.make_sequence(7, n_frames=3, height=128, width=160, max_disp=48.0)
+    preds = []
+    stats = run_sequence(model, seq, iters=6, device=dev, collect=preds)
+    assert len(stats.frames) == 3
+    for t in range(3):
+        tag = "clip" if t == 0 else "rp_clip"
+        assert epe(-preds[t], e2e_golden[f"{tag}_flow_{t}"]) <= 1e-4, t
+
+
+def test_e2e_c2_golden(dev, e2e_golden, model):
+    """BASELINE config 2, frame 0: 640x480, 32 iterations, vs the reference.  1e-3 EPE (north_star)."""
+    from tcs_mi355 import synth
+    fr = synth.make_sequence(2000, n_frames=1).frames[0]
+    out = model(D(fr.image1, dev)[None], D(fr.image2, dev)[None], iters=32, test_mode=True)
+    assert epe(out["flow_q"], e2e_golden["c2_flow_q"]) <= 1e-3
+
+
+def test_no_cpu_fallback(dev, model):
+    with pytest.raises(RuntimeError):
+        model(torch.zeros(1, 3, 64, 64), torch.zeros(1, 3, 64, 64), iters=1, test_mode=True)

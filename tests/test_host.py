@@ -1,0 +1,183 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/tcs_mi355.h declares
+(no compute calls without a GPU), the drop-in module tree matches the reference's state-dict keys,
+the harness maths, loud failure without a device, and the N>1 sharding/gather path on gloo."""
+import json
+import os
+import re
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _args(**kw):
+    from argparse import Namespace
+    d = dict(hidden_dims=[128] * 3, shared_backbone=True, corr_levels=4, corr_radius=4, n_downsample=2,
+             context_norm="none", slow_fast_gru=False, n_gru_layers=3, mixed_precision=False, init_thres=0.5)
+    d.update(kw)
+    return Namespace(**d)
+
+
+def test_library_exports_every_declared_symbol():
+    from tcs_mi355 import build, native
+    build.build(verbose=False)                      # cross-compiles for gfx950 without a GPU
+    header = open(os.path.join(ROOT, "include", "tcs_mi355.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(tcs_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = native.lib()
+    for name in declared:
+        assert hasattr(lib, name), f"libtcs_mi355.so lacks {name}"
+    assert declared == set(native.SIGNATURES), declared ^ set(native.SIGNATURES)
+    assert lib.tcs_abi_version() >= 1
+    assert lib.tcs_error_string(-1) == b"invalid argument"
+    # pure host-side size queries are safe without a GPU
+    assert lib.tcs_corr_level_bytes(1, 120, 160, 0) == 120 * 160 * 160 * 4
+    assert lib.tcs_corr_level_bytes(1, 120, 160, 3) == 120 * 20 * 160 * 4
+    assert lib.tcs_conv_packed_floats(256, 384, 3) == 384 * 9 * 256
+    assert lib.tcs_conv_packed_floats(1, 256, 3) == 256 * 9 * 32
+    assert lib.tcs_conv_packed_floats(64, 1, 7) == 32 * 49 * 64
+
+
+def test_conv_desc_layout_matches_header():
+    """ctypes mirror of struct tcs_conv_desc: same field order as the header."""
+    from tcs_mi355 import native
+    header = open(os.path.join(ROOT, "include", "tcs_mi355.h")).read()
+    body = header[header.index("typedef struct tcs_conv_desc {"):header.index("} tcs_conv_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(","):
+            fields.append(re.sub(r"\[.*?\]", "", part.strip().split()[-1].lstrip("*")))
+    assert fields == [f[0] for f in native.ConvDesc._fields_]
+
+
+@pytest.mark.parametrize("tag,kw", [("shared_backbone", {}), ("separate_fnet", dict(shared_backbone=False)),
+                                    ("context_norm_batch", dict(context_norm="batch"))])
+def test_state_dict_keys_match_reference(key_shapes, tag, kw):
+    from core.tc_stereo import TCStereo
+    sd = {k: list(v.shape) for k, v in TCStereo(_args(**kw)).state_dict().items()}
+    assert sd == key_shapes[tag]
+
+
+def test_synth_weights_are_deterministic_and_load_strict(key_shapes):
+    from core.tc_stereo import TCStereo
+    from tcs_mi355.weights import DAMPED_HEADS, synth_state_dict, synth_tensor
+    a = synth_state_dict(key_shapes["shared_backbone"])
+    b = synth_state_dict(key_shapes["shared_backbone"])
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    TCStereo(_args()).load_state_dict(a, strict=True)
+    k = DAMPED_HEADS[0]
+    assert a[k].std().item() < 0.1 * synth_tensor(k.replace("conv2", "conv1"), a[k].shape).std().item() * 2
+    assert a["update_block.gru08.convzr.bias"].abs().sum() == 0
+
+
+def test_no_cpu_fallback_and_inference_only():
+    from core.corr import CorrBlock1D
+    from core.tc_stereo import TCStereo
+    m = TCStereo(_args()).eval()
+    x = torch.zeros(1, 3, 64, 64)
+    with pytest.raises(NotImplementedError):
+        m(x, x, iters=1, test_mode=False)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        m(x, x, iters=1, test_mode=True)
+    with pytest.raises(RuntimeError, match="HIP device tensor"):
+        CorrBlock1D(torch.zeros(1, 8, 4, 16), torch.zeros(1, 8, 4, 16))
+
+
+def test_missing_library_is_loud(monkeypatch, tmp_path):
+    from tcs_mi355 import native
+    monkeypatch.setattr(native, "_LIB", None)
+    monkeypatch.setenv("TCS_MI355_LIB", str(tmp_path / "absent.so"))
+    with pytest.raises(native.NativeLibraryMissing):
+        native.lib()
+
+
+def test_input_padder_and_metrics():
+    from tcs_mi355.harness import FrameStats, InputPadder, SequenceStats, frame_metrics, reduce_stats
+    x = torch.arange(2 * 3 * 375 * 1242, dtype=torch.float32).reshape(2, 3, 375, 1242)
+    K = torch.tensor([[[721.5, 0, 609.6], [0, 721.5, 172.9], [0, 0, 1.0]]])
+    p = InputPadder(x.shape, divis_by=32)
+    (y,), K2 = p.pad(x, K=K)
+    assert tuple(y.shape) == (2, 3, 384, 1248)                       # KITTI: 1242x375 -> 1248x384
+    assert (p.left, p.right, p.top, p.bottom) == (3, 3, 4, 5)
+    assert K2[0, 0, 2].item() == pytest.approx(609.6 + 3) and K2[0, 1, 2].item() == pytest.approx(172.9 + 4)
+    assert torch.equal(y[..., 4:379, 3:1245], x)                     # interior untouched
+    assert torch.equal(y[..., 0, 3:1245], x[..., 0, :])              # replicate
+    z, K3 = p.unpad(y, K=K2)
+    assert torch.equal(z, x) and torch.allclose(K3, K)
+    q = InputPadder((1, 3, 240, 320), divis_by=32)
+    assert (q.top, q.bottom, q.left, q.right) == (8, 8, 0, 0)        # config 1: 240 -> 256 rows
+    k = InputPadder((1, 3, 375, 1242), mode="kitti", divis_by=32)
+    assert (k.top, k.bottom) == (0, 9)
+    gt = torch.tensor([[[[10.0, 200.0], [5.0, 1.0]]]])
+    pr = torch.tensor([[[[10.5, 0.0], [9.0, 1.0]]]])
+    fs = frame_metrics(pr, gt)                                       # 200 is invalid (>=192)
+    assert fs.mask_rate == pytest.approx(0.75)
+    assert fs.epe == pytest.approx((0.5 + 4.0 + 0.0) / 3)
+    assert fs.d1_weighted == pytest.approx((1 / 3) * 0.75) and fs.d3_weighted == pytest.approx((1 / 3) * 0.75)
+    assert frame_metrics(pr, torch.full_like(gt, 500.0)) is None
+    s1, s2 = SequenceStats([fs, fs]), SequenceStats([FrameStats(1.0, 0.5, 0.25, 1.0)])
+    r = reduce_stats([s1.vector(), s2.vector()])
+    assert r["frames"] == 3
+    assert r["epe"] == pytest.approx((2 * fs.epe + 1.0) / 3)
+    assert r["d1"] == pytest.approx(100 * ((2 * fs.d1_weighted + 0.5) / 3) / ((2 * 0.75 + 1.0) / 3))
+
+
+def test_synthetic_sequence_properties():
+    from tcs_mi355 import synth
+    seq = synth.make_sequence(3, n_frames=2, height=96, width=128, max_disp=48.0)
+    again = synth.make_sequence(3, n_frames=2, height=96, width=128, max_disp=48.0)
+    f = seq.frames[0]
+    assert f.image1.shape == (3, 96, 128) and f.image1.dtype == np.float32
+    assert np.array_equal(f.image1, again.frames[0].image1)          # deterministic
+    assert f.image1.min() >= 0 and f.image1.max() <= 255 and np.array_equal(f.image1, np.rint(f.image1))
+    assert 0 < f.disp_gt.min() and f.disp_gt.max() < 48.0
+    T0, T1 = seq.frames[0].T, seq.frames[1].T
+    assert np.allclose(T0, np.eye(4), atol=1e-6) and not np.allclose(T1, T0)
+    assert np.allclose(T1[:3, :3] @ T1[:3, :3].T, np.eye(3), atol=1e-5)
+    # stereo consistency: left pixel x matches right pixel x - disp where unoccluded
+    d = f.disp_gt[0]
+    ys, xs = np.mgrid[0:96, 0:128]
+    xr = np.rint(xs - d).astype(int)
+    ok = xr >= 0
+    err = np.abs(f.image1[:, ys[ok], xs[ok]] - f.image2[:, ys[ok], xr[ok]]).mean()
+    assert err < 12.0
+
+
+def test_two_rank_gloo_shard_and_gather(tmp_path):
+    """world_size 2 on gloo: round-robin sequence sharding + the single all_gather of statistics."""
+    script = tmp_path / "rank.py"
+    script.write_text(textwrap.dedent(f"""
+        import sys, json
+        sys.path.insert(0, {ROOT!r})
+        import tcs_paths; tcs_paths.add_product_path()
+        import numpy as np
+        from tcs_mi355 import dist as td
+        from tcs_mi355.harness import FrameStats, SequenceStats, reduce_stats
+        rank, world, local = td.init_from_env(force_backend="gloo")
+        mine = td.shard(list(range(5)), rank, world)
+        st = SequenceStats([FrameStats(float(s), 0.1 * s, 0.01 * s, 1.0) for s in mine])
+        vecs = td.gather_vectors(st.vector())
+        slow = td.max_over_ranks(1.0 + rank)
+        td.barrier()
+        if rank == 0:
+            print(json.dumps(dict(mine=mine, n=len(vecs), red=reduce_stats(vecs), slow=slow)))
+    """))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    res = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert res["mine"] == [0, 2, 4] and res["n"] == 2 and res["slow"] == 2.0
+    assert res["red"]["frames"] == 5
+    assert res["red"]["epe"] == pytest.approx(np.mean([0, 1, 2, 3, 4]))
