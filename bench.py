@@ -10,7 +10,7 @@ sequence per rank (no data-path collective; one all_gather of EPE statistics at 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 with `roofline` (corr lookup, HIP events in the timed region) and
+Prints ONE JSON line on rank 0 with `roofline` (corr lookup, device-clock stamps in the timed region) and
 `cpu_baseline` (the CPU oracle on the host cores, rank 0 / N=1 only).
 """
 import argparse
@@ -80,52 +80,23 @@ class ClipRunner:
         return out
 
 
-class LookupTimer:
-    """HIP events around every corr-lookup launch of the timed region (same stream as the kernels:
-    the library launches on torch's current stream)."""
-
-    def __init__(self):
-        from tcs_mi355 import ops
-        self.ops, self.orig, self.pairs, self.pixels, self.on = ops, ops.corr_lookup, [], 0, False
-
-    def __enter__(self):
-        def timed(pyr, coords, radius=4, out=None):
-            if not self.on:
-                return self.orig(pyr, coords, radius, out)
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            r = self.orig(pyr, coords, radius, out)
-            b.record()
-            self.pairs.append((a, b))
-            self.pixels = pyr.B * pyr.H * pyr.W
-            return r
-        self.ops.corr_lookup = timed
-        return self
-
-    def __exit__(self, *exc):
-        self.ops.corr_lookup = self.orig
-
-    def empty_bracket_us(self, n=200):
-        """Cost of an event pair with nothing between (subtracted as calibration)."""
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
-        for a, b in ev:
-            a.record()
-            b.record()
-        torch.cuda.synchronize()
-        return float(np.median([a.elapsed_time(b) for a, b in ev])) * 1e3
-
-    def result(self):
-        if not self.pairs:
-            return None
-        torch.cuda.synchronize()
-        us = np.array([a.elapsed_time(b) for a, b in self.pairs]) * 1e3
-        cal = self.empty_bracket_us()
-        dur_us = max(float(np.mean(us)) - cal, 1e-3)
-        alg_bytes = LOOKUP_BYTES_PER_PIXEL * self.pixels
-        achieved = alg_bytes / (dur_us * 1e-6) / 1e9
-        return {"bound": "hbm", "kernel": "k_corr_lookup<4>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_us": round(dur_us, 3),
-                "event_pair_overhead_us": round(cal, 3), "launches": len(self.pairs), "algorithmic_bytes_per_launch": alg_bytes}
+def lookup_roofline(probe, snapshots):
+    """`roofline` object for the corr lookup from the in-kernel device clock stamps collected over the
+    timed region: per launch, duration = max(workgroup end) - min(workgroup start) on the 100 MHz
+    s_memrealtime clock (the same interval rocprofv3's kernel trace reports).  HIP event pairs cannot
+    resolve this kernel: an event pair costs ~5 us on this stack, more than the kernel itself."""
+    durs = []
+    for snap in snapshots:
+        durs += probe.durations_us(snap)
+    if not durs:
+        return None
+    dur_us = float(np.mean(durs))
+    alg_bytes = LOOKUP_BYTES_PER_PIXEL * probe.pixels
+    achieved = alg_bytes / (dur_us * 1e-6) / 1e9
+    return {"bound": "hbm", "kernel": "k_corr_lookup<4>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_us": round(dur_us, 3),
+            "min_launch_us": round(float(np.min(durs)), 3), "launches": len(durs), "algorithmic_bytes_per_launch": alg_bytes,
+            "timer": "in-kernel s_memrealtime stamps (100 MHz), every lookup launch of the timed region"}
 
 
 def cpu_baseline(W, seq, gpu_preds, n_frames=2):
@@ -153,6 +124,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch kernels eagerly instead of replaying HIP graphs")
     a = ap.parse_args()
 
     from tcs_mi355 import dist as tdist
@@ -167,23 +139,30 @@ def main():
     dev = torch.device("cuda", local)
 
     model, W = build_model(dev)
+    model.use_hip_graph = not a.eager
     seq = synth.make_sequence(2000 + rank, n_frames=CLIP_LEN, height=HEIGHT, width=WIDTH, max_disp=MAX_DISP)
     runner = ClipRunner(model, seq, dev, ITERS)
 
-    with LookupTimer() as lt, torch.no_grad():
-        for _ in range(a.warmup):
+    from tcs_mi355 import ops
+    probe = ops.LookupProbe(dev, slots=64)
+    ops.LOOKUP_PROBE = probe             # before the first forward: the stamp slots are baked into the captured graphs
+    snaps = []
+    with torch.no_grad():
+        for _ in range(max(a.warmup, 2)):          # >= 2 so that both branches (first frame / temporal) are captured
             runner.step()
+        probe.reset()
         torch.cuda.synchronize()
         tdist.barrier()
-        lt.on = True
         t0 = time.perf_counter()
         for _ in range(a.steps):
             runner.step()
+            snaps.append(probe.buf.clone())        # stream-ordered 300 KB copy + clear; no host sync
+            probe.reset()
         torch.cuda.synchronize()
         tdist.barrier()
         elapsed = time.perf_counter() - t0
-        lt.on = False
-        roof = lt.result()
+    roof = lookup_roofline(probe, snaps)
+    ops.LOOKUP_PROBE = None
 
     elapsed = tdist.max_over_ranks(elapsed)
     total_pairs = a.steps * max(world, 1)
@@ -210,7 +189,8 @@ def main():
             "n_gpus": max(world, 1), "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 640x480 synthetic sequence len=10, D=192, 32 iters, one sequence per GPU",
-                       "frames_per_rank": a.steps, "weights": "key-seeded synthetic (tcs_mi355.weights)"},
+                       "frames_per_rank": a.steps, "weights": "key-seeded synthetic (tcs_mi355.weights)",
+                       "launch": "eager" if a.eager else "hip-graph replay"},
             "roofline": roof, "cpu_baseline": cpu, "epe_vs_oracle_first_frames": epe_vs_oracle,
             "ranks_frames": [int(v[0]) for v in vecs],
         }

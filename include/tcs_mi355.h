@@ -77,7 +77,12 @@ float* tcs_corr_ws_level0(void* workspace);
  * Channel = level*(2r+1) + tap, taps ascending in dx; samples outside a level read 0.
  */
 int tcs_corr_lookup(const float* pyr0, const float* pyr1, const float* pyr2, const float* pyr3,
-                    const float* coords, int B, int H, int W, int radius, float* out, tcs_stream_t stream);
+                    const float* coords, int B, int H, int W, int radius, float* out,
+                    unsigned long long* stamps, tcs_stream_t stream);
+/* Measurement hook: when `stamps` is non-NULL (device uint64[2 * tcs_corr_lookup_blocks(B,H,W)], zeroed by the
+ * caller) every workgroup records the device wall clock (s_memrealtime, 100 MHz) at its start and end, so the
+ * launch duration = max(end) - min(start) can be read without a profiler.  NULL in production. */
+int tcs_corr_lookup_blocks(int B, int H, int W);
 
 /* ------------------------------------------------------------------------------------------------
  * Temporal warp                                 (core/utils/geo_utils.py, core/utils/splatting/softsplat.py)
@@ -117,6 +122,12 @@ int tcs_softsplat_sum(const float* in, const float* flow, int B, int C, int H, i
 /* get_backward_grid (geo_utils.py:201-236): grid [B,2,H,W] of previous-frame pixel coordinates. */
 int tcs_backward_grid(const float* disp, const float* T_rel, const float* K, const float* K_inv,
                       const float* baseline, int B, int H, int W, float* grid, tcs_stream_t stream);
+
+/* Camera algebra of TCStereo.forward (tc_stereo.py:121-127,159) on the device, no host round trip:
+ * K_scaled = K * [scale,scale,1]^T (rows 0,1), its inverse, and — when T / T_prev are given —
+ * T_rel = T * inv(T_prev) (geo_utils.py:148-155) and T_back = T_prev * inv(T).  K [B,3,3], T [B,4,4]. */
+int tcs_pose_prepare(const float* K, const float* T, const float* T_prev, float scale, int B,
+                     float* K_scaled, float* K_scaled_inv, float* T_rel, float* T_back, tcs_stream_t stream);
 
 /* bilinear_sampler (core/utils/utils.py:82-97): img [B,C,Hi,Wi] sampled at grid [B,2,Ho,Wo] (x,y in
  * pixels), zeros outside, align_corners=True -> out [B,C,Ho,Wo]. */

@@ -11,6 +11,7 @@ Inference only: `test_mode=False` (training outputs and losses, train_stereo.py)
 There is no CPU path: tensors must live on a HIP device and the library must be built.
 """
 import contextlib
+import os
 
 import torch
 import torch.nn as nn
@@ -92,34 +93,50 @@ class TCStereo(nn.Module):
         """Disparity of a stereo pair, optionally conditioned on the previous frame (`params`):
         K [b,3,3], T / previous_T [b,4,4] world->camera, baseline [b], last_disp (= previous 'flow_q'),
         last_net_list, fmap1.  Returns {'flow' [b,1,H,W] (negative disparity, clipped at 0),
-        'flow_q' [b,1,H/4,W/4], 'net_list', 'fmap1'} (tc_stereo.py:96-244)."""
+        'flow_q' [b,1,H/4,W/4], 'net_list', 'fmap1'} (tc_stereo.py:96-244).
+
+        The whole frame is a fixed launch sequence with no host round trip, so by default it is
+        captured once per (shape, iters, branch) into a HIP graph and replayed (tcs_mi355.graph);
+        set TCS_MI355_GRAPH=0 or `model.use_hip_graph = False` for eager launches."""
         if not test_mode:
             raise NotImplementedError("TCStereo on MI355X is inference-only: call with test_mode=True")
         if iters < 1:
             raise ValueError("iters must be >= 1")
         if not image1.is_cuda:
             raise RuntimeError("TCStereo.forward needs HIP device tensors; there is no CPU fallback")
+        temporal = None
+        if params is not None:
+            temporal = (params["K"], params["T"], params["previous_T"], params["baseline"], params["last_disp"],
+                        list(params["last_net_list"]), params["fmap1"])
+        if getattr(self, "use_hip_graph", None) is None:
+            self.use_hip_graph = os.environ.get("TCS_MI355_GRAPH", "1") != "0"
+        if self.use_hip_graph:
+            if getattr(self, "_graphs", None) is None:
+                from tcs_mi355.graph import FrameGraphs
+                self._graphs = FrameGraphs(self._frame)
+            return self._graphs(image1, image2, iters, temporal)
+        return self._frame(image1, image2, iters, temporal)
+
+    def _frame(self, image1, image2, iters, temporal):
+        """One frame as a pure launch sequence (tensors in, tensors out; capturable)."""
         a = self.args
         image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
         image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
         cnet_list, fmap1, fmap2 = self._extract(image1, image2)
 
-        first = params is None
+        first = temporal is None
         corr_fn = CorrBlock1D(fmap1, fmap2, radius=a.corr_radius, num_levels=a.corr_levels, thres=a.init_thres,
                               want_argmax=first)
         if first:
             sparse_disp, cost, sparse_mask = corr_fn.argmax_disp()
             last_net_list = None
         else:
-            K = params["K"]
-            K_scale = K * torch.tensor([self.scale_rate, self.scale_rate, 1.0], device=K.device).view(1, 3, 1)
-            K_scale_inv = torch.linalg.inv(K_scale)
-            T, previous_T, baseline = params["T"], params["previous_T"], params["baseline"]
-            relative_T = torch.matmul(T, torch.linalg.inv(previous_T))
-            last_net_list = params["last_net_list"]
+            K, T, previous_T, baseline, last_disp, last_net_list, last_fmap1 = temporal
+            # K_scale, its inverse, T @ inv(previous_T), previous_T @ inv(T): one tiny kernel, no host sync
+            K_scale, K_scale_inv, relative_T, back_T = ops.pose_prepare(K, T, previous_T, self.scale_rate)
             # warp + normalise + cosine cost in one launch sequence; the warped feature map is never materialised
             sparse_disp, _, sparse_mask, cost = ops.warp_forward(
-                (-params["last_disp"]).float().contiguous(), params["fmap1"].float().contiguous(), relative_T, K_scale,
+                (-last_disp).float().contiguous(), last_fmap1.float().contiguous(), relative_T, K_scale,
                 K_scale_inv, baseline, cur_fmap=fmap1, want_fmap=False)
 
         inp_list = [torch.relu(x[1]) for x in cnet_list]
@@ -133,7 +150,6 @@ class TCStereo(nn.Module):
         if last_net_list is None:
             warped = [torch.zeros_like(x) for x in net_list]
         else:
-            back_T = torch.matmul(previous_T, torch.linalg.inv(T))
             grid = ops.backward_grid(disp_init, back_T, K_scale, K_scale_inv, baseline)
             warped = []
             for i, net in enumerate(last_net_list):

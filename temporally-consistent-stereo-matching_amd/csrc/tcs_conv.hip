@@ -79,36 +79,66 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
 
+    // ---- staging plan, fixed for the whole K loop ----------------------------------------------
+    // input: thread -> one halo position (row r, column cc) of channel lane `sub`; per chunk it only
+    // adds the channel base to a precomputed pixel offset (no div/mod in the loop).
+    constexpr int R = (256 / IN_CH) > 0 ? (256 / IN_CH) : 1;      // channel lanes (3x3: 1, 1x1: 2)
+    constexpr int IN_PT = (KC + R - 1) / R;                       // input values per thread per chunk
+    constexpr int W4 = KC * TAPS * NT / 4;                        // float4s of one weight chunk
+    constexpr int W_PT = (W4 + 255) / 256;
+    const int sub = tid / IN_CH, pos = tid - sub * IN_CH;
+    const bool in_active = sub < R;
+    const int sr = pos / IW, sc = pos - sr * IW;
+    const int gy = y0 - HALO + sr, gx = x0 - HALO + sc;
+    const bool in_ok = in_active && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const size_t pixoff = in_ok ? (size_t)gy * W + gx : 0;
+    const float* wsrc = a.w + ct * NT;
+
+    float in_reg[IN_PT];
+    float4 w_reg[W_PT];
+
+    // (macros, not lambdas: by-reference lambda captures kept these arrays in scratch memory)
+#define TCS_LOAD_CHUNK(C0)                                                                              \
+    {                                                                                                   \
+        _Pragma("unroll") for (int j = 0; j < IN_PT; ++j) {                                             \
+            const int g = (C0) + sub + j * R;                                                           \
+            float v = 0.f;                                                                              \
+            if (in_ok && sub + j * R < KC && g < a.Cin) {                                               \
+                const float* sp = a.src[0];                                                             \
+                int cb = 0, cs = a.src_ch[0];                                                           \
+                if (g >= a.src_end[0]) { sp = a.src[1]; cb = a.src_end[0]; cs = a.src_ch[1]; }          \
+                if (g >= a.src_end[1]) { sp = a.src[2]; cb = a.src_end[1]; cs = a.src_ch[2]; }          \
+                if (g >= a.src_end[2]) { sp = a.src[3]; cb = a.src_end[2]; cs = a.src_ch[3]; }          \
+                v = sp[((size_t)b * cs + (g - cb)) * HW + pixoff];                                      \
+            }                                                                                           \
+            in_reg[j] = v;                                                                              \
+        }                                                                                               \
+        _Pragma("unroll") for (int j = 0; j < W_PT; ++j) {                                              \
+            const int idx = tid + 256 * j;                                                              \
+            const int row = idx / (NT / 4), q = idx % (NT / 4);                                         \
+            w_reg[j] = (idx < W4)                                                                       \
+                ? *reinterpret_cast<const float4*>(wsrc + ((size_t)(C0) * TAPS + row) * a.CoutPad + q * 4) \
+                : make_float4(0.f, 0.f, 0.f, 0.f);                                                      \
+        }                                                                                               \
+    }
+#define TCS_STORE_CHUNK()                                                                               \
+    {                                                                                                   \
+        _Pragma("unroll") for (int j = 0; j < IN_PT; ++j)                                               \
+            if (in_active && sub + j * R < KC) s_in[(sub + j * R) * IN_CH + pos] = in_reg[j];           \
+        _Pragma("unroll") for (int j = 0; j < W_PT; ++j) {                                              \
+            const int idx = tid + 256 * j;                                                              \
+            if (idx < W4) *reinterpret_cast<float4*>(s_w + idx * 4) = w_reg[j];                         \
+        }                                                                                               \
+    }
+
+    // ---- K loop: global loads of chunk i+1 are in flight while the matrix cores work on chunk i ----
     const int cin_loop = (a.Cin + KC - 1) / KC * KC;
+    TCS_LOAD_CHUNK(0)
+    TCS_STORE_CHUNK()
+    __syncthreads();
     for (int c0 = 0; c0 < cin_loop; c0 += KC) {
-        __syncthreads();
-        // ---- stage the input halo tile of KC channels (virtual concat over the sources) ----
-        for (int idx = tid; idx < KC * IN_CH; idx += 256) {
-            const int k = idx / IN_CH, rem = idx - k * IN_CH;
-            const int r = rem / IW, cc = rem - r * IW;
-            const int gy = y0 - HALO + r, gx = x0 - HALO + cc, g = c0 + k;
-            float v = 0.f;
-            if (g < a.Cin && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                const float* sp = a.src[0];
-                int cb = 0, cs = a.src_ch[0];
-                if (g >= a.src_end[0]) { sp = a.src[1]; cb = a.src_end[0]; cs = a.src_ch[1]; }
-                if (g >= a.src_end[1]) { sp = a.src[2]; cb = a.src_end[1]; cs = a.src_ch[2]; }
-                if (g >= a.src_end[2]) { sp = a.src[3]; cb = a.src_end[2]; cs = a.src_ch[3]; }
-                v = sp[((size_t)b * cs + (g - cb)) * HW + (size_t)gy * W + gx];
-            }
-            s_in[idx] = v;
-        }
-        // ---- stage the weight slice: KC*TAPS rows of NT floats, 16 B per lane ----
-        {
-            const float* wsrc = a.w + (size_t)c0 * TAPS * a.CoutPad + ct * NT;
-            for (int idx = tid; idx < KC * TAPS * (NT / 4); idx += 256) {
-                const int row = idx / (NT / 4), q = idx - row * (NT / 4);
-                const float4 val = *reinterpret_cast<const float4*>(wsrc + (size_t)row * a.CoutPad + q * 4);
-                *reinterpret_cast<float4*>(s_w + row * NT + q * 4) = val;
-            }
-        }
-        __syncthreads();
-        // ---- MFMA over (tap, channel pair) ----
+        const bool has_next = c0 + KC < cin_loop;
+        if (has_next) TCS_LOAD_CHUNK(c0 + KC)
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
             const int dy = t / KS, dx = t % KS;
@@ -124,7 +154,15 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a) {
                 }
             }
         }
+        if (has_next) {
+            __syncthreads();            // every wave has finished reading this chunk
+            TCS_STORE_CHUNK()           // (waits here for the prefetched registers)
+            __syncthreads();
+        }
     }
+
+#undef TCS_LOAD_CHUNK
+#undef TCS_STORE_CHUNK
 
     // ---- epilogue ----
     const int px = x0 + l31, py = y0 + wave;
@@ -214,12 +252,19 @@ static int launch_mfma(const ConvArgs& a, hipStream_t s) {
     return tcs_launch_status();
 }
 
-template <int KS, int KC, int EPI>
-static int launch_by_tile(const ConvArgs& a, int nt, hipStream_t s) {
+// KC per tile shape: the narrow tile gets a deeper chunk so that each barrier pair covers >= 72 MFMAs per wave.
+template <int KS, int EPI>
+static int launch_by_tile(ConvArgs& a, int nt_pack, hipStream_t s) {
+    // Occupancy-driven tile choice: the widest cout tile (most input reuse) that still yields >= 2 blocks per CU;
+    // small feature maps (1/8, 1/16 scale) fall back to 32-wide tiles so every SIMD gets a wave.
+    int nt = nt_pack;
+    while (nt > 32 && (long long)a.npatch * a.B * (a.CoutPad / nt) < 512) nt >>= 1;
+    a.nct = a.CoutPad / nt;
+    constexpr int KCW = (KS == 1) ? 32 : 8, KCN = (KS == 1) ? 32 : 16;
     switch (nt) {
-        case 128: return launch_mfma<KS, 4, KC, EPI>(a, s);
-        case 64: return launch_mfma<KS, 2, KC, EPI>(a, s);
-        default: return launch_mfma<KS, 1, KC, EPI>(a, s);
+        case 128: return launch_mfma<KS, 4, KCW, EPI>(a, s);
+        case 64: return launch_mfma<KS, 2, KCW, EPI>(a, s);
+        default: return launch_mfma<KS, 1, KCN, EPI>(a, s);
     }
 }
 
@@ -275,8 +320,8 @@ int tcs_conv2d(const tcs_conv_desc* d, tcs_stream_t stream) {
             else return TCS_EUNSUPPORTED;
             return tcs_launch_status();
         }
-        if (d->ksize == 3) return launch_by_tile<3, 8, TCS_EPI_LINEAR>(a, nt, s);
-        if (d->ksize == 1) return launch_by_tile<1, 32, TCS_EPI_LINEAR>(a, nt, s);
+        if (d->ksize == 3) return launch_by_tile<3, TCS_EPI_LINEAR>(a, nt, s);
+        if (d->ksize == 1) return launch_by_tile<1, TCS_EPI_LINEAR>(a, nt, s);
         return TCS_EUNSUPPORTED;
     }
     // GRU epilogues: hidden = Cout/2 (ZR) or Cout (Q); tiles must not straddle the z|r boundary
@@ -284,15 +329,15 @@ int tcs_conv2d(const tcs_conv_desc* d, tcs_stream_t stream) {
     if (d->epilogue == TCS_EPI_GRU_ZR) {
         if (!d->out2 || (d->Cout & 1)) return TCS_EINVAL;
         a.hidden = d->Cout / 2;
-        if (d->ksize == 3) return launch_by_tile<3, 8, TCS_EPI_GRU_ZR>(a, nt, s);
-        if (d->ksize == 1) return launch_by_tile<1, 32, TCS_EPI_GRU_ZR>(a, nt, s);
+        if (d->ksize == 3) return launch_by_tile<3, TCS_EPI_GRU_ZR>(a, nt, s);
+        if (d->ksize == 1) return launch_by_tile<1, TCS_EPI_GRU_ZR>(a, nt, s);
         return TCS_EUNSUPPORTED;
     }
     if (d->epilogue == TCS_EPI_GRU_Q) {
         if (!d->z) return TCS_EINVAL;
         a.hidden = d->Cout;
-        if (d->ksize == 3) return launch_by_tile<3, 8, TCS_EPI_GRU_Q>(a, nt, s);
-        if (d->ksize == 1) return launch_by_tile<1, 32, TCS_EPI_GRU_Q>(a, nt, s);
+        if (d->ksize == 3) return launch_by_tile<3, TCS_EPI_GRU_Q>(a, nt, s);
+        if (d->ksize == 1) return launch_by_tile<1, TCS_EPI_GRU_Q>(a, nt, s);
         return TCS_EUNSUPPORTED;
     }
     return TCS_EINVAL;

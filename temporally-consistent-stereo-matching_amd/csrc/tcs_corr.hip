@@ -208,6 +208,7 @@ struct LookupArgs {
     const float* pyr[4];
     const float* coords;
     float* out;
+    unsigned long long* stamps;     // nullable: [gridDim.x][2] device wall-clock (100 MHz) at block start / end
     int B, H, W, radius;
 };
 
@@ -215,6 +216,7 @@ template <int R>
 __global__ __launch_bounds__(256) void k_corr_lookup(LookupArgs a) {
     const int lane = threadIdx.x & 63;
     const int level = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     const int HW = a.H * a.W;
     const long long p = (long long)blockIdx.x * 64 + lane;
     if (p >= (long long)a.B * HW) return;
@@ -263,6 +265,10 @@ __global__ __launch_bounds__(256) void k_corr_lookup(LookupArgs a) {
             o[(size_t)t * HW] = (1.f - fr) * prev + fr * nxt;
             prev = nxt;
         }
+    }
+    if (a.stamps && lane == 0) {
+        __builtin_amdgcn_s_waitcnt(0);      // this wave's stores have been issued and acknowledged
+        atomicMax(&a.stamps[2 * blockIdx.x + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }
 }
 
@@ -323,13 +329,19 @@ int tcs_corr_build(const float* fmap1, const float* fmap2, int B, int C, int H, 
     return tcs_launch_status();
 }
 
+int tcs_corr_lookup_blocks(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return tcs_cdiv((long long)B * H * W, 64);
+}
+
 int tcs_corr_lookup(const float* pyr0, const float* pyr1, const float* pyr2, const float* pyr3,
-                    const float* coords, int B, int H, int W, int radius, float* out, tcs_stream_t stream) {
+                    const float* coords, int B, int H, int W, int radius, float* out, unsigned long long* stamps,
+                    tcs_stream_t stream) {
     if (!pyr0 || !pyr1 || !pyr2 || !pyr3 || !coords || !out) return TCS_EINVAL;
     if (B <= 0 || H <= 0 || W < 8 || radius < 0 || radius > 16) return TCS_EINVAL;
     LookupArgs a;
     a.pyr[0] = pyr0; a.pyr[1] = pyr1; a.pyr[2] = pyr2; a.pyr[3] = pyr3;
-    a.coords = coords; a.out = out; a.B = B; a.H = H; a.W = W; a.radius = radius;
+    a.coords = coords; a.out = out; a.stamps = stamps; a.B = B; a.H = H; a.W = W; a.radius = radius;
     const int blocks = tcs_cdiv((long long)B * H * W, 64);
     if (radius == 4)
         hipLaunchKernelGGL(k_corr_lookup<4>, dim3(blocks), dim3(256), 0, tcs_stream(stream), a);

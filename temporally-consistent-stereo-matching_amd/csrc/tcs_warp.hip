@@ -233,6 +233,59 @@ __global__ __launch_bounds__(256) void k_resize_bilinear(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// camera algebra of tc_stereo.py:121-127,159 on the device (one thread per batch element): keeps the
+// frame free of host round trips (torch.linalg.inv synchronises) so it can be captured in a HIP graph.
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__device__ void invert_small(const float* __restrict__ m, float* __restrict__ inv) {
+    float a[N][2 * N];
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) { a[i][j] = m[i * N + j]; a[i][N + j] = (i == j) ? 1.f : 0.f; }
+    for (int c = 0; c < N; ++c) {                      // Gauss-Jordan, partial pivoting
+        int p = c;
+        for (int r = c + 1; r < N; ++r) if (fabsf(a[r][c]) > fabsf(a[p][c])) p = r;
+        if (p != c) for (int j = 0; j < 2 * N; ++j) { const float t = a[c][j]; a[c][j] = a[p][j]; a[p][j] = t; }
+        const float piv = 1.0f / a[c][c];
+        for (int j = 0; j < 2 * N; ++j) a[c][j] *= piv;
+        for (int r = 0; r < N; ++r) {
+            if (r == c) continue;
+            const float f = a[r][c];
+            for (int j = 0; j < 2 * N; ++j) a[r][j] = fmaf(-f, a[c][j], a[r][j]);
+        }
+    }
+    for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) inv[i * N + j] = a[i][N + j];
+}
+
+__device__ void matmul4(const float* a, const float* b, float* o) {
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            float s = 0.f;
+            for (int k = 0; k < 4; ++k) s = fmaf(a[i * 4 + k], b[k * 4 + j], s);
+            o[i * 4 + j] = s;
+        }
+}
+
+__global__ void k_pose_prepare(const float* __restrict__ K, const float* __restrict__ T, const float* __restrict__ Tp, float scale,
+                               int B, float* __restrict__ Ks, float* __restrict__ Ksi, float* __restrict__ Trel,
+                               float* __restrict__ Tback) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float ks[9], inv3[9];
+    for (int i = 0; i < 9; ++i) ks[i] = K[b * 9 + i] * (i < 6 ? scale : 1.f);     // rows 0,1 scaled (tc_stereo.py:122)
+    invert_small<3>(ks, inv3);
+    for (int i = 0; i < 9; ++i) { Ks[b * 9 + i] = ks[i]; Ksi[b * 9 + i] = inv3[i]; }
+    if (T && Tp) {
+        float inv4[16], o[16];
+        invert_small<4>(Tp + b * 16, inv4);
+        matmul4(T + b * 16, inv4, o);                                             // geo_utils.py:148-155
+        for (int i = 0; i < 16; ++i) Trel[b * 16 + i] = o[i];
+        invert_small<4>(T + b * 16, inv4);
+        matmul4(Tp + b * 16, inv4, o);                                            // tc_stereo.py:159
+        for (int i = 0; i < 16; ++i) Tback[b * 16 + i] = o[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -343,6 +396,16 @@ int tcs_grid_halve(const float* grid, int B, int H, int W, float* out, tcs_strea
     const int Ho = H / 2, Wo = W / 2;
     hipLaunchKernelGGL(k_resize_bilinear, dim3(tcs_cdiv((long long)Ho * Wo, 256), B * 2), dim3(256), 0, tcs_stream(stream),
                        grid, 2, H, W, Ho, Wo, 0.5f, out);
+    return tcs_launch_status();
+}
+
+int tcs_pose_prepare(const float* K, const float* T, const float* T_prev, float scale, int B,
+                     float* K_scaled, float* K_scaled_inv, float* T_rel, float* T_back, tcs_stream_t stream) {
+    if (!K || !K_scaled || !K_scaled_inv || B <= 0) return TCS_EINVAL;
+    if ((T == nullptr) != (T_prev == nullptr)) return TCS_EINVAL;
+    if (T && (!T_rel || !T_back)) return TCS_EINVAL;
+    hipLaunchKernelGGL(k_pose_prepare, dim3(tcs_cdiv(B, 64)), dim3(64), 0, tcs_stream(stream), K, T, T_prev, scale, B,
+                       K_scaled, K_scaled_inv, T_rel, T_back);
     return tcs_launch_status();
 }
 

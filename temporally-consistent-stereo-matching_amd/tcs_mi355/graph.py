@@ -1,0 +1,77 @@
+"""HIP-graph replay of a whole TC-Stereo frame.
+
+One frame is ~1,800 kernel launches with static shapes and no host decision inside, so the launch
+sequence is captured once per (input shape, iteration count, first-frame / temporal branch) and
+replayed.  Inputs are copied into the graph's static buffers, outputs are cloned out, so callers
+keep ordinary tensor semantics (the temporal state they pass back next frame is theirs).  The
+library kernels are capture-safe by construction (no allocation, no sync, stream-ordered memset
+only — include/tcs_mi355.h); the PyTorch-ROCm parts (extractor, U-Nets) are captured by torch.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Callable, Dict, Optional
+
+import torch
+
+
+def _flatten(temporal):
+    if temporal is None:
+        return []
+    K, T, Tp, base, last_disp, nets, fmap1 = temporal
+    return [K, T, Tp, base, last_disp, *nets, fmap1]
+
+
+def _unflatten(flat):
+    if not flat:
+        return None
+    return (flat[0], flat[1], flat[2], flat[3], flat[4], list(flat[5:-1]), flat[-1])
+
+
+class _Entry:
+    def __init__(self, graph, static_in, static_out):
+        self.graph, self.static_in, self.static_out = graph, static_in, static_out
+
+
+class FrameGraphs:
+    def __init__(self, frame_fn: Callable, warmup: int = 2):
+        self.frame_fn, self.warmup = frame_fn, warmup
+        self.cache: Dict[tuple, Optional[_Entry]] = {}
+
+    def _key(self, image1, iters, flat):
+        return (tuple(image1.shape), image1.device.index, int(iters), tuple(tuple(t.shape) for t in flat))
+
+    def _capture(self, image1, image2, iters, flat) -> Optional[_Entry]:
+        static_in = [image1.clone(), image2.clone()] + [t.detach().float().clone() for t in flat]
+        run = lambda: self.frame_fn(static_in[0], static_in[1], iters, _unflatten(static_in[2:]))
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(self.warmup):        # packs weights, lets MIOpen pick algorithms, sizes the pools
+                    run()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = run()
+            return _Entry(g, static_in, out)
+        except Exception as e:  # capture is an optimisation: the eager HIP path computes the same thing
+            warnings.warn(f"HIP graph capture failed ({type(e).__name__}: {e}); running this shape with eager launches")
+            torch.cuda.synchronize()
+            return None
+
+    def __call__(self, image1, image2, iters, temporal):
+        flat = _flatten(temporal)
+        key = self._key(image1, iters, flat)
+        if key not in self.cache:
+            self.cache[key] = self._capture(image1, image2, iters, flat)
+        e = self.cache[key]
+        if e is None:
+            return self.frame_fn(image1, image2, iters, temporal)
+        for dst, src in zip(e.static_in, [image1, image2, *flat]):
+            dst.copy_(src)
+        e.graph.replay()
+        o = e.static_out
+        return {"flow": o["flow"].clone(), "flow_q": o["flow_q"].clone(), "net_list": [t.clone() for t in o["net_list"]],
+                "fmap1": o["fmap1"].clone()}

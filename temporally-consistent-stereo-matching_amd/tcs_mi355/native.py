@@ -46,7 +46,9 @@ SIGNATURES = {
     "tcs_corr_build": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp,
                                c_fp, c_fp, c_fp, c_fp, c_fp]),
     "tcs_corr_ws_level0": (c_fp, [c_fp]),
-    "tcs_corr_lookup": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp]),
+    "tcs_corr_lookup": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp]),
+    "tcs_corr_lookup_blocks": (c_int, [c_int, c_int, c_int]),
+    "tcs_pose_prepare": (c_int, [c_fp, c_fp, c_fp, c_f, c_int, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "tcs_warp_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
     "tcs_warp_forward": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp,
                                  c_fp, c_fp]),

