@@ -33,6 +33,10 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 LOOKUP_BYTES_PER_PIXEL = 308    # 4 levels x 10 taps x 4 B + 4 B coord + 36 x 4 B out
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def build_model(dev):
     from argparse import Namespace
 
@@ -104,8 +108,14 @@ def cpu_baseline(W, seq, gpu_preds, n_frames=2):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import tcs_oracle as oracle
     from tcs_mi355.harness import run_sequence
-    cores = os.cpu_count() or 1
+    # the GPU box exposes every host core but grants a 16-core share: more threads than that only thrash
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, os.cpu_count() or 1, int(os.environ.get("TCS_BENCH_CPU_THREADS", "16"))))
     torch.set_num_threads(cores)
+    log(f"cpu baseline: oracle on {cores} threads, {n_frames} frames ...")
     sub = type(seq)(seq.frames[:n_frames], seq.K, seq.baseline)
     preds = []
     t0 = time.perf_counter()
@@ -138,6 +148,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    log("building model + synthetic clip")
     model, W = build_model(dev)
     model.use_hip_graph = not a.eager
     seq = synth.make_sequence(2000 + rank, n_frames=CLIP_LEN, height=HEIGHT, width=WIDTH, max_disp=MAX_DISP)
@@ -148,8 +159,10 @@ def main():
     ops.LOOKUP_PROBE = probe             # before the first forward: the stamp slots are baked into the captured graphs
     snaps = []
     with torch.no_grad():
+        log("warm-up (captures the HIP graphs)")
         for _ in range(max(a.warmup, 2)):          # >= 2 so that both branches (first frame / temporal) are captured
             runner.step()
+        log(f"timing {a.steps} steps")
         probe.reset()
         torch.cuda.synchronize()
         tdist.barrier()
@@ -176,6 +189,7 @@ def main():
         from tcs_mi355.harness import run_sequence
         sub = type(seq)(seq.frames[:2], seq.K, seq.baseline)
         gpu_preds = []
+        log("accuracy sample on the GPU")
         run_sequence(model, sub, iters=ITERS, device=dev, collect=gpu_preds)
         cpu, epes = cpu_baseline(W, seq, gpu_preds, 2)
         epe_vs_oracle = [round(e, 6) for e in epes]

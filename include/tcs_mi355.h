@@ -190,6 +190,9 @@ int tcs_resize_bilinear(const float* x, int B, int C, int H, int W, int Ho, int 
 #define TCS_EPI_GRU_ZR 1         /* first half: z = sigmoid(. + cz) -> out; second half: r = sigmoid(. + cr), out2 = r*h */
 #define TCS_EPI_GRU_Q 2          /* q = tanh(. + cq); out = blend(z, h, q)                           */
 
+#define TCS_MATH_F32 0           /* v_mfma_f32_32x32x2_f32: fp32 in, fp32 accumulate                                  */
+#define TCS_MATH_F16X3 1         /* fp16 hi/lo split, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate (~2^-21) */
+
 #define TCS_MAX_SRC 4
 
 typedef struct tcs_conv_desc {
@@ -213,12 +216,19 @@ typedef struct tcs_conv_desc {
     float* out;              /* LINEAR: [B,out_ctot,H,W] written at channel offset out_coff. GRU_ZR: z. GRU_Q: new h */
     int out_ctot, out_coff;
     float* out2;             /* GRU_ZR: r*h */
+    int math;                /* TCS_MATH_F32: weights from tcs_pack_conv_weight; TCS_MATH_F16X3: from ..._f16x3 */
+    float weight_unscale;    /* F16X3: 2^-scale_log2 given to tcs_pack_conv_weight_f16x3 */
 } tcs_conv_desc;
 
 /* packed weight size in floats for a [Cout,Cin,k,k] convolution */
 size_t tcs_conv_packed_floats(int Cout, int Cin, int ksize);
 /* OIHW device weights -> the kernel's layout ([Cin_pad][k*k][Cout_pad], zero padded) */
 int tcs_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int ksize, float* packed, tcs_stream_t stream);
+/* fp16-split weights: OIHW * 2^scale_log2, split into (hi, lo) halves, in the kernel's LDS image order.
+ * Choose scale_log2 so that max|w| * 2^scale_log2 is ~2^10..2^14 (keeps the lo halves normal). ksize in {1,3}. */
+size_t tcs_conv_packed_floats_f16x3(int Cout, int Cin, int ksize);
+int tcs_pack_conv_weight_f16x3(const float* w_oihw, int Cout, int Cin, int ksize, int scale_log2, float* packed,
+                               tcs_stream_t stream);
 /* nn.Conv2d(k, padding=k/2) + fused epilogue; covers ConvGRU / Lightfuse / HiddenstateUpdater /
  * BasicMotionEncoder / FlowHead / the stride-1 convs of DispRefine and DispGradPredictor (core/update.py). */
 int tcs_conv2d(const tcs_conv_desc* desc, tcs_stream_t stream);

@@ -9,6 +9,8 @@ iteration of the reference (update.py:27-35,58-67,78-86,155-158) are gone.
 Still on PyTorch-ROCm (MIOpen) for now: the stride-2 convs and the transposed-conv + InstanceNorm
 up-blocks of the two U-Nets (DispGradPredictor, DisparityCompletor) — SURVEY.md §8f N3/N4.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -20,14 +22,21 @@ from tcs_mi355 import ops
 # ---------------------------------------------------------------------------------------------
 # packed-weight cache: one device-side repack per conv, redone only if the parameter changes
 # ---------------------------------------------------------------------------------------------
+# Contraction arithmetic of tcs_conv2d: "f16x3" = fp16 hi/lo split on the half-precision matrix pipe with fp32
+# accumulation (fp32-equivalent accuracy, ~5x the fp32 MFMA rate), "f32" = fp32-in/fp32-out MFMA.  A layer can pin
+# its own mode with `conv._tcs_math`.
+CONV_MATH = os.environ.get("TCS_MI355_MATH", "f16x3")
+
+
 def packed(conv: nn.Conv2d) -> ops.PackedConv:
     w, b = conv.weight, conv.bias
-    key = (w.data_ptr(), w._version, w.device, None if b is None else (b.data_ptr(), b._version))
+    math = getattr(conv, "_tcs_math", None) or CONV_MATH
+    key = (w.data_ptr(), w._version, w.device, None if b is None else (b.data_ptr(), b._version), math)
     hit = getattr(conv, "_tcs_packed", None)
     if hit is None or hit[0] != key:
         if conv.stride != (1, 1) or conv.dilation != (1, 1) or conv.groups != 1 or conv.padding != (conv.kernel_size[0] // 2,) * 2:
             raise NotImplementedError(f"tcs_conv2d covers stride-1 'same' convolutions, got {conv}")
-        hit = (key, ops.pack_conv(w, b))
+        hit = (key, ops.pack_conv(w, b, math))
         conv._tcs_packed = hit
     return hit[1]
 
@@ -205,6 +214,8 @@ class DispGradPredictor(nn.Module):
         self.args = args
         self.conv_grad_stem = _two(2, 32, 32)
         self.conv_grad_candidate_stem = _two(32, 64, 64)
+        # its input (-n_x/n_z of neighbour cross products, geo_utils.py:99-100) is unbounded: keep fp32 operands
+        self.conv_grad_candidate_stem[0]._tcs_math = "f32"
         relu = lambda: nn.ReLU(inplace=True)
         self.conv_4_4 = nn.Sequential(_conv(160, 64, 3), relu())
         self.conv_4_8 = nn.Sequential(_conv(64, 96, 3, 2), relu())

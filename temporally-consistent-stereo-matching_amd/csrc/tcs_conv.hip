@@ -17,44 +17,7 @@
 //
 // Block -> (patch, cout tile): cout tile = blockIdx.x % n_tiles.  Blocks b and b+8 share an XCD
 // (round-robin dispatch), so with 1, 2, 4 or 8 cout tiles every XCD's L2 holds a single weight slice.
-#include "tcs_common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct ConvArgs {
-    const float* src[TCS_MAX_SRC];
-    int src_ch[TCS_MAX_SRC];
-    int src_end[TCS_MAX_SRC];
-    const float* w;
-    const float* bias;
-    int B, H, W, Cin, Cout, CoutPad;
-    int act;
-    float post_scale;
-    const float* add1;
-    const float* add2;
-    const float* h;
-    const float* z;
-    int keep_z, hidden;
-    float* out;
-    int out_ctot, out_coff;
-    float* out2;
-    int npx, npatch, nct;
-};
-
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-    switch (act) {
-        case TCS_ACT_RELU: return fmaxf(v, 0.f);
-        case TCS_ACT_SIGMOID: return sigmoidf_(v);
-        case TCS_ACT_TANH: return tanhf(v);
-        case TCS_ACT_LEAKY: return v > 0.f ? v : 0.01f * v;
-        default: return v;
-    }
-}
-
-static inline int cout_tile(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
-static inline int round_up(int a, int m) { return (a + m - 1) / m * m; }
+#include "tcs_conv_common.h"
 
 template <int KS, int MT, int KC, int EPI>
 __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a) {
@@ -174,27 +137,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a) {
         for (int reg = 0; reg < 16; ++reg) {
             const int co = ct * NT + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
             if (co >= a.Cout) continue;
-            float v = acc[m][reg] + (a.bias ? a.bias[co] : 0.f);
-            if (EPI == TCS_EPI_LINEAR) {
-                if (a.add1) v += a.add1[((size_t)b * a.Cout + co) * HW + pix];
-                v = apply_act(v, a.act) * a.post_scale;
-                a.out[((size_t)b * a.out_ctot + a.out_coff + co) * HW + pix] = v;
-            } else if (EPI == TCS_EPI_GRU_ZR) {
-                if (co < a.hidden) {
-                    const size_t o = ((size_t)b * a.hidden + co) * HW + pix;
-                    if (a.add1) v += a.add1[o];
-                    a.out[o] = sigmoidf_(v);
-                } else {
-                    const size_t o = ((size_t)b * a.hidden + (co - a.hidden)) * HW + pix;
-                    if (a.add2) v += a.add2[o];
-                    a.out2[o] = sigmoidf_(v) * a.h[o];
-                }
-            } else {
-                const size_t o = ((size_t)b * a.hidden + co) * HW + pix;
-                if (a.add1) v += a.add1[o];
-                const float q = tanhf(v), zz = a.z[o], hh = a.h[o];
-                a.out[o] = a.keep_z ? zz * hh + (1.f - zz) * q : (1.f - zz) * hh + zz * q;
-            }
+            conv_epilogue<EPI>(a, b, co, pix, HW, acc[m][reg]);
         }
     }
 }
@@ -308,7 +251,22 @@ int tcs_conv2d(const tcs_conv_desc* d, tcs_stream_t stream) {
     a.npx = tcs_cdiv(d->W, 32);
     a.npatch = a.npx * tcs_cdiv(d->H, 4);
     a.nct = a.CoutPad / nt;
+    a.w_unscale = 1.0f;
     hipStream_t s = tcs_stream(stream);
+
+    if (d->math == TCS_MATH_F16X3) {
+        // fp16-split matrix-core path (tcs_conv_f16.hip); weights must come from tcs_pack_conv_weight_f16x3
+        if (d->Cin == 1 || (d->ksize != 1 && d->ksize != 3)) return TCS_EUNSUPPORTED;
+        if (d->epilogue == TCS_EPI_LINEAR && (d->out_ctot < d->out_coff + d->Cout || d->out_coff < 0)) return TCS_EINVAL;
+        if (d->epilogue != TCS_EPI_LINEAR && !d->h) return TCS_EINVAL;
+        if (d->epilogue == TCS_EPI_GRU_ZR && (!d->out2 || (d->Cout & 1))) return TCS_EINVAL;
+        if (d->epilogue == TCS_EPI_GRU_Q && !d->z) return TCS_EINVAL;
+        a.hidden = d->epilogue == TCS_EPI_GRU_ZR ? d->Cout / 2 : (d->epilogue == TCS_EPI_GRU_Q ? d->Cout : 0);
+        a.CoutPad = round_up(d->Cout, 32);
+        a.w_unscale = d->weight_unscale;
+        return tcs_conv_f16x3_launch(a, d->ksize, d->epilogue, s);
+    }
+    if (d->math != TCS_MATH_F32) return TCS_EINVAL;
 
     if (d->epilogue == TCS_EPI_LINEAR) {
         if (d->out_ctot < d->out_coff + d->Cout || d->out_coff < 0) return TCS_EINVAL;

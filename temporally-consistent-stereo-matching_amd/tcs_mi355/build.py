@@ -14,7 +14,7 @@ PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libtcs_mi355.so")
-SOURCES = ["tcs_corr.hip", "tcs_warp.hip", "tcs_stencil.hip", "tcs_conv.hip"]
+SOURCES = ["tcs_corr.hip", "tcs_warp.hip", "tcs_stencil.hip", "tcs_conv.hip", "tcs_conv_f16.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 
 

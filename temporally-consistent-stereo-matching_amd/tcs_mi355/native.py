@@ -34,6 +34,7 @@ class ConvDesc(C.Structure):
         ("addend", c_fp), ("addend2", c_fp), ("h", c_fp), ("z", c_fp),
         ("blend_keep_z", c_int),
         ("out", c_fp), ("out_ctot", c_int), ("out_coff", c_int), ("out2", c_fp),
+        ("math", c_int), ("weight_unscale", c_f),
     ]
 
 
@@ -67,6 +68,8 @@ SIGNATURES = {
     "tcs_resize_bilinear": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp]),
     "tcs_conv_packed_floats": (c_sz, [c_int, c_int, c_int]),
     "tcs_pack_conv_weight": (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_fp]),
+    "tcs_conv_packed_floats_f16x3": (c_sz, [c_int, c_int, c_int]),
+    "tcs_pack_conv_weight_f16x3": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp]),
     "tcs_conv2d": (c_int, [C.POINTER(ConvDesc), c_fp]),
 }
 

@@ -282,28 +282,51 @@ def resize_bilinear(x, Ho: int, Wo: int, out=None):
 # ---------------------------------------------------------------------------------------------
 # convolutions on the matrix cores
 # ---------------------------------------------------------------------------------------------
+MATH_F32, MATH_F16X3 = 0, 1
+
+
 @dataclass
 class PackedConv:
-    weight: torch.Tensor           # kernel layout (tcs_pack_conv_weight)
+    weight: torch.Tensor           # kernel layout (tcs_pack_conv_weight / tcs_pack_conv_weight_f16x3)
     bias: Optional[torch.Tensor]
     cout: int
     cin: int
     ksize: int
+    math: int = MATH_F32
+    unscale: float = 1.0
 
 
-def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> PackedConv:
+def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], math: str = "f32") -> PackedConv:
+    """math='f32': fp32 MFMA kernel.  math='f16x3': fp16 hi/lo split kernel (fp32-equivalent accuracy);
+    falls back to 'f32' for the shapes the split kernel does not cover (Cin == 1, 7x7)."""
     cout, cin, kh, kw = (int(s) for s in weight.shape)
     if kh != kw:
         raise ValueError("square kernels only")
     L = nv.lib()
+    w = weight.detach().float().contiguous()
+    b = None if bias is None else bias.detach().float().contiguous()
+    if math == "f16x3" and cin > 1 and kh in (1, 3):
+        n = L.tcs_conv_packed_floats_f16x3(cout, cin, kh)
+        wmax = float(w.abs().max())
+        s_log2 = 0 if wmax == 0.0 else int(12 - math_floor_log2(wmax))           # max|w| * 2^s in [2^12, 2^13)
+        s_log2 = max(-40, min(40, s_log2))
+        packed = torch.empty(n, dtype=torch.float32, device=w.device)
+        nv.check(L.tcs_pack_conv_weight_f16x3(nv.ptr(w, "weight"), cout, cin, kh, s_log2, nv.ptr(packed), nv.stream()),
+                 "tcs_pack_conv_weight_f16x3")
+        return PackedConv(packed, b, cout, cin, kh, MATH_F16X3, 2.0 ** (-s_log2))
+    if math not in ("f32", "f16x3"):
+        raise ValueError(f"unknown math mode {math!r}")
     n = L.tcs_conv_packed_floats(cout, cin, kh)
     if n == 0:
         raise ValueError(f"unsupported convolution [{cout},{cin},{kh},{kw}]")
-    w = weight.detach().float().contiguous()
     packed = torch.empty(n, dtype=torch.float32, device=w.device)
     nv.check(L.tcs_pack_conv_weight(nv.ptr(w, "weight"), cout, cin, kh, nv.ptr(packed), nv.stream()), "tcs_pack_conv_weight")
-    b = None if bias is None else bias.detach().float().contiguous()
     return PackedConv(packed, b, cout, cin, kh)
+
+
+def math_floor_log2(x: float) -> int:
+    import math as _m
+    return int(_m.floor(_m.log2(x)))
 
 
 def _desc(pc: PackedConv, srcs: Sequence[torch.Tensor]) -> nv.ConvDesc:
@@ -326,6 +349,7 @@ def _desc(pc: PackedConv, srcs: Sequence[torch.Tensor]) -> nv.ConvDesc:
     d.bias = nv.ptr(pc.bias)
     d.B, d.H, d.W, d.Cin, d.Cout, d.ksize = B, H, W, pc.cin, pc.cout, pc.ksize
     d.post_scale = 1.0
+    d.math, d.weight_unscale = pc.math, pc.unscale
     return d
 
 

@@ -241,7 +241,8 @@ def test_stencils_golden(dev, ops_golden, model):
     dict(B=1, cins=(256,), cout=1, k=3, H=6, W=32),                    # flow head conv2
     dict(B=1, cins=(128,), cout=384, k=3, H=30, W=40),                 # context_zqr conv: 3 cout tiles
 ])
-def test_conv2d_vs_torch(dev, cfg):
+@pytest.mark.parametrize("math", ["f32", "f16x3"])
+def test_conv2d_vs_torch(dev, cfg, math):
     from tcs_mi355 import ops
     gen = torch.Generator().manual_seed(cfg["cout"] + cfg["k"])
     cin = sum(cfg["cins"])
@@ -250,7 +251,8 @@ def test_conv2d_vs_torch(dev, cfg):
     xs = [torch.randn(cfg["B"], c, cfg["H"], cfg["W"], generator=gen) for c in cfg["cins"]]
     add = torch.randn(cfg["B"], cfg["cout"], cfg["H"], cfg["W"], generator=gen)
     ref = F.conv2d(torch.cat(xs, 1).double(), w.double(), b.double(), padding=cfg["k"] // 2)
-    pc = ops.pack_conv(D(w, dev), D(b, dev))
+    pc = ops.pack_conv(D(w, dev), D(b, dev), math)
+    assert pc.math == (ops.MATH_F16X3 if (math == "f16x3" and cin > 1 and cfg["k"] != 7) else ops.MATH_F32)
     got = ops.conv2d(pc, [D(x, dev) for x in xs])
     assert maxdiff(got, ref) <= 2e-5
     got = ops.conv2d(pc, [D(x, dev) for x in xs], act="relu", addend=D(add, dev), post_scale=0.25)
@@ -372,3 +374,24 @@ def test_graph_replay_matches_eager(dev, model):
         # not bit-identical: MIOpen may choose another algorithm for the extractor convs under capture, and the
         # splat's float atomics commit in a different order from run to run
         assert epe(graphed[t], eager[t]) <= 1e-5 and epe(again[t], eager[t]) <= 1e-5, t
+
+
+def test_f16x3_split_is_fp32_grade(dev):
+    """The fp16-split contraction must be as accurate as fp32 arithmetic, also for awkward magnitudes:
+    tiny and large activations, weights far from 1, long K (gru08: 3456)."""
+    from tcs_mi355 import ops
+    gen = torch.Generator().manual_seed(1)
+    B, cin, cout, H, W = 1, 384, 64, 8, 32
+    x = torch.randn(B, cin, H, W, generator=gen)
+    x[:, :64] *= 1e-4                                   # fp16-subnormal territory for the lo halves
+    x[:, 64:128] *= 300.0                               # large values (disparities)
+    w = torch.randn(cout, cin, 3, 3, generator=gen) * 0.02
+    ref = F.conv2d(x.double(), w.double(), None, padding=1)
+    scale = float(ref.abs().max())
+    e32 = maxdiff(ops.conv2d(ops.pack_conv(D(w, dev), None, "f32"), [D(x, dev)]), ref) / scale
+    e16 = maxdiff(ops.conv2d(ops.pack_conv(D(w, dev), None, "f16x3"), [D(x, dev)]), ref) / scale
+    cpu = maxdiff(F.conv2d(x, w, None, padding=1), ref) / scale
+    print(f"relative max error: fp32 MFMA {e32:.2e}, f16x3 {e16:.2e}, torch CPU fp32 {cpu:.2e}")
+    # K = 3456 products per output: the fp32 MFMA is a sequential fmaf chain (error grows with K); the split
+    # kernel adds exact fp16xfp16 products in fp32 and must be at least as good
+    assert e32 <= 1e-5 and e16 <= 1e-5 and e16 <= 1.5 * e32

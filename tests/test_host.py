@@ -181,3 +181,49 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
     assert res["mine"] == [0, 2, 4] and res["n"] == 2 and res["slow"] == 2.0
     assert res["red"]["frames"] == 5
     assert res["red"]["epe"] == pytest.approx(np.mean([0, 1, 2, 3, 4]))
+
+
+def test_formats_known_answers(tmp_path):
+    """N2 file formats.  The reference readers (core/utils/frame_utils.py) cannot be imported here (cv2 /
+    imageio are absent), so these are known-answer checks against scipy's Rotation — the function the
+    reference itself calls (frame_utils.py:244) — and round trips: parity unpinned by reference outputs."""
+    from scipy.spatial.transform import Rotation
+    from tcs_mi355 import formats
+    rng = np.random.default_rng(0)
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    t = rng.normal(size=3)
+    assert np.allclose(formats.quat_to_matrix(*q), Rotation.from_quat(q).as_matrix(), atol=1e-12)
+    # frame_utils.py:245-257 restated with scipy
+    R = Rotation.from_quat(q).as_matrix()
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = R.T, -R.T @ t
+    m = np.zeros((4, 4))
+    m[0, 1] = m[1, 2] = m[2, 0] = m[3, 3] = 1
+    want = m @ T
+    p = tmp_path / "pose_left.txt"
+    p.write_text(" ".join(f"{v:.12f}" for v in (*t, *q)) + "\n" + "0 0 0 0 0 0 1\n")
+    got = formats.read_tartanair_extrinsic(str(p))
+    assert len(got) == 2 and np.allclose(got[0], want, atol=1e-9)
+    assert np.allclose(got[1], m)                                     # identity pose -> pure axis permutation
+    # KITTI: 3x4 camera->world rows, inverted
+    P = np.eye(4)
+    P[:3, :3], P[:3, 3] = R, t
+    k = tmp_path / "kitti.txt"
+    k.write_text(" ".join(f"{v:.12f}" for v in P[:3].ravel()) + "\n")
+    assert np.allclose(formats.read_kitti_extrinsic(str(k))[0] @ P, np.eye(4), atol=1e-9)
+    s = tmp_path / "camera_data.txt"
+    s.write_text("Frame 1\nL " + " ".join(f"{v:.12f}" for v in P.ravel()) + "\nR " + " ".join(["0"] * 16) + "\n\n")
+    sf = formats.read_sceneflow_pose(str(s))
+    assert len(sf) == 1 and np.allclose(sf[0] @ P, np.eye(4), atol=1e-9)
+    # TartanAir depth -> disparity
+    d, v = formats.disp_from_tartanair_depth(np.array([[1.0, 80.0], [0.0, 1e9]]))
+    assert d[0, 0] == pytest.approx(80.0 / 1.00001) and d[0, 1] == pytest.approx(1.0, rel=1e-6) and v.all()
+    # PFM round trip (bottom-up rows, little endian) + a hand-built big-endian file
+    img = rng.normal(size=(5, 7)).astype(np.float32)
+    f = tmp_path / "d.pfm"
+    formats.write_pfm(str(f), img)
+    assert np.array_equal(formats.read_pfm(str(f)), img)
+    be = tmp_path / "be.pfm"
+    be.write_bytes(b"Pf\n2 2\n1.0\n" + np.array([[3, 4], [1, 2]], ">f4").tobytes())
+    assert np.array_equal(formats.read_pfm(str(be)), np.array([[1, 2], [3, 4]], np.float32))
