@@ -161,6 +161,10 @@ class TCStereo(nn.Module):
 
         coords0, coords1 = self.initialize_flow(fmap1)
         coords1 = (coords0 - disp_init).contiguous()
+        trace = getattr(self, "_trace", None)          # debugging hook (eager mode only): intermediate tensors
+        if trace is not None:
+            trace.update(sparse_disp=sparse_disp, cost=cost, sparse_mask=sparse_mask, disp_init=disp_init,
+                         net0=[t.clone() for t in net_list], iters=[])
 
         n3 = a.n_gru_layers == 3
         refined = up_mask = None
@@ -180,6 +184,9 @@ class TCStereo(nn.Module):
             delta_disp = refined - disp_q
             net_list = [self.hiddenstate_update(net_list[0], delta_disp), net_list[1], net_list[2]]
             coords1 = (coords0 - refined).contiguous()
+            if trace is not None:
+                trace["iters"].append(dict(corr=corr, delta=delta_flow, disp_q=disp_q, refined=refined,
+                                           net=[t.clone() for t in net_list]))
 
         flow_up, flow_q = ops.convex_upsample(refined.contiguous(), up_mask)
         return {"flow": flow_up, "flow_q": flow_q, "net_list": [x.detach() for x in net_list], "fmap1": fmap1.detach()}

@@ -137,6 +137,14 @@ __global__ __launch_bounds__(256) void k_splat(const float* __restrict__ in, con
     }
 }
 
+// explicit zero fill of the splat accumulator.  (A captured hipMemsetAsync node did not re-clear the
+// 20 MB accumulator on HIP-graph replays on ROCm 7.2: the second replay of a frame summed into the previous
+// frame's values.  A kernel node has no such ambiguity.)
+__global__ __launch_bounds__(256) void k_zero_fill(float4* __restrict__ p, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // normalise (softsplat.py:257-270, 'clipeps'), split, and the temporal cost (tc_stereo.py:139-140)
 __global__ __launch_bounds__(256) void k_warp_finish(const float* __restrict__ acc, const float* __restrict__ cur_fmap,
                                                      int C, int HW, float* __restrict__ out_disp, float* __restrict__ out_fmap,
@@ -355,7 +363,10 @@ int tcs_warp_forward(const float* prev_disp, const float* prev_fmap, const float
     WarpWs w = carve(workspace, B, C, H, W);
     int rc = geometry(prev_disp, T_rel, K, K_inv, baseline, B, H, W, w, s);
     if (rc) return rc;
-    if (hipMemsetAsync(w.acc, 0, w.acc_bytes, s) != hipSuccess) return TCS_ELAUNCH;
+    {
+        const size_t n4 = (w.acc_bytes + 15) / 16;          // the carve is 256-byte aligned and padded
+        hipLaunchKernelGGL(k_zero_fill, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<float4*>(w.acc), n4);
+    }
     const int nb = tcs_cdiv((long long)H * W, 256);
     const int cpg = 16, groups = tcs_cdiv(C + 2, cpg);
     hipLaunchKernelGGL(k_splat<1>, dim3(nb, B, groups), dim3(256), 0, s, prev_fmap, w.flow, w.cur_disp, w.valid, w.mean,

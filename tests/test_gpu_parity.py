@@ -395,3 +395,20 @@ def test_f16x3_split_is_fp32_grade(dev):
     # K = 3456 products per output: the fp32 MFMA is a sequential fmaf chain (error grows with K); the split
     # kernel adds exact fp16xfp16 products in fp32 and must be at least as good
     assert e32 <= 1e-5 and e16 <= 1e-5 and e16 <= 1.5 * e32
+
+
+def test_graph_replay_full_size_many_frames(dev, model):
+    """Regression: at 640x480 the temporal graph must stay correct on its 2nd, 3rd ... replay (the splat
+    accumulator has to be re-cleared inside the graph).  4 frames, 2 iterations, graph vs eager."""
+    from tcs_mi355 import synth
+    from tcs_mi355.harness import run_sequence
+    seq = synth.make_sequence(2000, n_frames=4, height=480, width=640, max_disp=192.0)
+    model.use_hip_graph = False
+    eager = []
+    run_sequence(model, seq, iters=2, device=dev, collect=eager)
+    model.use_hip_graph = True
+    for rep in range(2):
+        graphed = []
+        run_sequence(model, seq, iters=2, device=dev, collect=graphed)
+        for t in range(4):
+            assert epe(graphed[t], eager[t]) <= 1e-5, (rep, t)
