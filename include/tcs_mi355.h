@@ -189,6 +189,8 @@ int tcs_resize_bilinear(const float* x, int B, int C, int H, int W, int Ho, int 
 #define TCS_EPI_LINEAR 0         /* out = act(conv + bias + addend) * post_scale                   */
 #define TCS_EPI_GRU_ZR 1         /* first half: z = sigmoid(. + cz) -> out; second half: r = sigmoid(. + cr), out2 = r*h */
 #define TCS_EPI_GRU_Q 2          /* q = tanh(. + cq); out = blend(z, h, q)                           */
+#define TCS_EPI_DECONV2X 3       /* ConvTranspose2d(k=4, stride 2, pad 1, no bias): weights from
+                                    tcs_pack_deconv4x4s2_f16x3, out [B, Cout/4, 2H, 2W]   (F16X3 only)      */
 
 #define TCS_MATH_F32 0           /* v_mfma_f32_32x32x2_f32: fp32 in, fp32 accumulate                                  */
 #define TCS_MATH_F16X3 1         /* fp16 hi/lo split, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate (~2^-21) */
@@ -216,6 +218,7 @@ typedef struct tcs_conv_desc {
     float* out;              /* LINEAR: [B,out_ctot,H,W] written at channel offset out_coff. GRU_ZR: z. GRU_Q: new h */
     int out_ctot, out_coff;
     float* out2;             /* GRU_ZR: r*h */
+    int stride;              /* 0 or 1: 'same' convolution; 2: 3x3 stride-2 pad-1 (F16X3 only), output (H-1)/2+1 x (W-1)/2+1 */
     int math;                /* TCS_MATH_F32: weights from tcs_pack_conv_weight; TCS_MATH_F16X3: from ..._f16x3 */
     float weight_unscale;    /* F16X3: 2^-scale_log2 given to tcs_pack_conv_weight_f16x3 */
 } tcs_conv_desc;
@@ -229,6 +232,16 @@ int tcs_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int ksize, floa
 size_t tcs_conv_packed_floats_f16x3(int Cout, int Cin, int ksize);
 int tcs_pack_conv_weight_f16x3(const float* w_oihw, int Cout, int Cin, int ksize, int scale_log2, float* packed,
                                tcs_stream_t stream);
+/* nn.ConvTranspose2d(Cin, Cout, 4, stride 2, padding 1, bias=False) weights [Cin,Cout,4,4] -> the F16X3 layout of
+ * the equivalent 3x3 convolution with 4*Cout outputs (one group per output parity); use with TCS_EPI_DECONV2X,
+ * desc.Cout = 4*Cout, ksize = 3.  (core/utils/basic_layers.py:17-21,57) */
+size_t tcs_deconv_packed_floats_f16x3(int Cin, int Cout);
+int tcs_pack_deconv4x4s2_f16x3(const float* w_iohw, int Cin, int Cout, int scale_log2, float* packed, float* scratch_oihw,
+                               tcs_stream_t stream);
+/* nn.InstanceNorm2d (affine=False, eps, biased variance) + activation + optional addend, per (b, c) plane:
+ * out = act((x - mean) / sqrt(var + eps)) + addend      (basic_layers.py:28-35,65-76; update.py:325-367) */
+int tcs_instance_norm(const float* x, int B, int C, int H, int W, float eps, int act, const float* addend, float* out,
+                      tcs_stream_t stream);
 /* nn.Conv2d(k, padding=k/2) + fused epilogue; covers ConvGRU / Lightfuse / HiddenstateUpdater /
  * BasicMotionEncoder / FlowHead / the stride-1 convs of DispRefine and DispGradPredictor (core/update.py). */
 int tcs_conv2d(const tcs_conv_desc* desc, tcs_stream_t stream);

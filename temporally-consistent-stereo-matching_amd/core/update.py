@@ -34,15 +34,47 @@ def packed(conv: nn.Conv2d) -> ops.PackedConv:
     key = (w.data_ptr(), w._version, w.device, None if b is None else (b.data_ptr(), b._version), math)
     hit = getattr(conv, "_tcs_packed", None)
     if hit is None or hit[0] != key:
-        if conv.stride != (1, 1) or conv.dilation != (1, 1) or conv.groups != 1 or conv.padding != (conv.kernel_size[0] // 2,) * 2:
-            raise NotImplementedError(f"tcs_conv2d covers stride-1 'same' convolutions, got {conv}")
+        if conv.stride not in ((1, 1), (2, 2)) or conv.dilation != (1, 1) or conv.groups != 1 or \
+                conv.padding != (conv.kernel_size[0] // 2,) * 2:
+            raise NotImplementedError(f"tcs_conv2d covers stride-1/2 'same'-padded convolutions, got {conv}")
         hit = (key, ops.pack_conv(w, b, math))
         conv._tcs_packed = hit
     return hit[1]
 
 
 def hip_conv(conv, srcs, act="none", **kw):
-    return ops.conv2d(packed(conv), [s.float().contiguous() for s in srcs], act=act, **kw)
+    return ops.conv2d(packed(conv), [s.float().contiguous() for s in srcs], act=act, stride=conv.stride[0], **kw)
+
+
+def hip_ok_stride2() -> bool:
+    """Stride-2 and transposed convolutions exist only on the fp16-split kernel; with TCS_MI355_MATH=f32 they stay on MIOpen."""
+    return CONV_MATH == "f16x3"
+
+
+def packed_deconv(deconv: nn.ConvTranspose2d) -> ops.PackedConv:
+    w = deconv.weight
+    key = (w.data_ptr(), w._version, w.device)
+    hit = getattr(deconv, "_tcs_packed", None)
+    if hit is None or hit[0] != key:
+        if deconv.kernel_size != (4, 4) or deconv.stride != (2, 2) or deconv.padding != (1, 1) or deconv.bias is not None:
+            raise NotImplementedError(f"tcs deconv covers ConvTranspose2d(4, stride 2, pad 1, bias=False), got {deconv}")
+        hit = (key, ops.pack_deconv4x4s2(w))
+        deconv._tcs_packed = hit
+    return hit[1]
+
+
+def hip_up_block(block: Conv2x_IN, x, rem):
+    """Conv2x_IN(deconv=True, concat=False) (basic_layers.py:38-77) on the HIP library:
+    transposed conv -> InstanceNorm -> LeakyReLU -> (+ rem) -> 3x3 conv [-> InstanceNorm] -> LeakyReLU."""
+    y = ops.deconv4x4s2(packed_deconv(block.conv1.conv), [x.float().contiguous()])
+    if y.shape != rem.shape:
+        y = F.interpolate(ops.instance_norm(y, act="leaky"), size=rem.shape[-2:], mode="nearest") + rem
+    else:
+        y = ops.instance_norm(y, act="leaky", addend=rem.float().contiguous())
+    if block.conv2.use_in:
+        z = hip_conv(block.conv2.conv, [y])
+        return ops.instance_norm(z, act="leaky" if block.conv2.relu else "none")
+    return hip_conv(block.conv2.conv, [y], act="leaky" if block.conv2.relu else "none")
 
 
 def hip_seq(seq: nn.Sequential, srcs, last_act="none"):
@@ -228,7 +260,10 @@ class DispGradPredictor(nn.Module):
         self.conv_out = nn.Sequential(_conv(64, 64, 3), relu())
 
     def _up(self, block: Conv2x_IN, x, rem):
-        """Conv2x_IN with the transposed conv + InstanceNorm on MIOpen and the 3x3 conv2 on MFMA."""
+        """Conv2x_IN: all-HIP with the fp16-split kernels; with TCS_MI355_MATH=f32 the transposed conv + InstanceNorm
+        stay on MIOpen and only the 3x3 conv2 runs on MFMA."""
+        if hip_ok_stride2():
+            return hip_up_block(block, x, rem)
         y = block.conv1(x)
         if y.shape != rem.shape:
             y = F.interpolate(y, size=rem.shape[-2:], mode="nearest")
@@ -241,9 +276,10 @@ class DispGradPredictor(nn.Module):
         x4_grad = hip_seq(self.conv_grad_stem, [g5])
         x4_cand = hip_seq(self.conv_grad_candidate_stem, [cands])
         x4 = hip_seq(self.conv_4_4, [x4_grad, x4_cand, clist[0]])
-        x8 = self.conv_4_8(x4)                                    # stride 2: MIOpen
+        s2 = hip_ok_stride2()
+        x8 = hip_seq(self.conv_4_8, [x4]) if s2 else self.conv_4_8(x4)          # 3x3 stride 2
         x8 = hip_seq(self.conv_8_8, [x8, clist[1]])
-        x16 = self.conv_8_16(x8)                                  # stride 2: MIOpen
+        x16 = hip_seq(self.conv_8_16, [x8]) if s2 else self.conv_8_16(x8)       # 3x3 stride 2
         x16 = hip_seq(self.conv_16_16, [x16, clist[2]])
         x8_up = self._up(self.conv_16_8, x16, x8)
         x4_up = self._up(self.conv_8_4, x8_up, x4)
@@ -310,7 +346,30 @@ class DisparityCompletor(nn.Module):
         self.conv_out8_disp = cin_block(192, 192, 128)
         self.conv_out4_disp = cin_block(192, 192, 128)
 
+    def _cin(self, seq, srcs):
+        """conv -> InstanceNorm -> ReLU -> conv blocks (update.py:325-367)."""
+        return hip_conv(seq[3], [ops.instance_norm(hip_conv(seq[0], srcs), act="relu")])
+
+    def _forward_hip(self, disp, cost, mask, ctx):
+        d = (disp / 10).float().contiguous()
+        stems = [hip_seq(self.conv_disp_stem, [d]), hip_seq(self.conv_cost_stem, [cost.float().contiguous()]),
+                 hip_seq(self.conv_mask_stem, [(mask - 0.5).float().contiguous()])]
+        x4_disp = hip_seq(self.conv_disp_fuse, stems)
+        x4 = self._cin(self.conv_4_4, [x4_disp, ctx[0]])
+        x8 = self._cin(self.conv_8_8, [self._cin(self.conv_4_8, [x4]), ctx[1]])
+        x16_out = self._cin(self.conv_16_16, [self._cin(self.conv_8_16, [x8]), ctx[2]])
+        x8_out = hip_up_block(self.conv_16_8, x16_out, x8)
+        x4_out = hip_up_block(self.conv_8_4, x8_out, x4)
+        disp_mono = hip_seq(self.disp_head, [x4_out])
+        w = hip_conv(self.w_head[2], [hip_conv(self.w_head[0], [x4_out], act="relu")], act="sigmoid")
+        completed = (w * d + (1 - w) * disp_mono) * 10
+        nets = [self._cin(self.conv_out4_disp, [x4_out, ctx[0]]), self._cin(self.conv_out8_disp, [x8_out, ctx[1]]),
+                self._cin(self.conv_out16_disp, [x16_out, ctx[2]])]
+        return completed, disp_mono * 10, w, nets
+
     def forward(self, disp, cost, mask, context_list):
+        if hip_ok_stride2() and disp.is_cuda:
+            return self._forward_hip(disp, cost, mask, [c.float().contiguous() for c in context_list])
         d = disp / 10
         x4_disp = self.conv_disp_fuse(torch.cat((self.conv_disp_stem(d), self.conv_cost_stem(cost),
                                                  self.conv_mask_stem(mask - 0.5)), 1))

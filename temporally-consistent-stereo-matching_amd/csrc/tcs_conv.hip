@@ -58,46 +58,38 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a) {
     const float* wsrc = a.w + ct * NT;
 
     float in_reg[IN_PT];
-    float4 w_reg[W_PT];
+    f32x4 w_reg[W_PT];
 
     // (macros, not lambdas: by-reference lambda captures kept these arrays in scratch memory)
 #define TCS_LOAD_CHUNK(C0)                                                                              \
     {                                                                                                   \
         _Pragma("unroll") for (int j = 0; j < IN_PT; ++j) {                                             \
             const int g = (C0) + sub + j * R;                                                           \
-            float v = 0.f;                                                                              \
-            if (in_ok && sub + j * R < KC && g < a.Cin) {                                               \
-                const float* sp = a.src[0];                                                             \
-                int cb = 0, cs = a.src_ch[0];                                                           \
-                if (g >= a.src_end[0]) { sp = a.src[1]; cb = a.src_end[0]; cs = a.src_ch[1]; }          \
-                if (g >= a.src_end[1]) { sp = a.src[2]; cb = a.src_end[1]; cs = a.src_ch[2]; }          \
-                if (g >= a.src_end[2]) { sp = a.src[3]; cb = a.src_end[2]; cs = a.src_ch[3]; }          \
-                v = sp[((size_t)b * cs + (g - cb)) * HW + pixoff];                                      \
-            }                                                                                           \
-            in_reg[j] = v;                                                                              \
+            /* unconditional load from a clamped (valid) address; zero-selected in TCS_STORE_CHUNK, so nothing waits \
+               for the value before the MFMA phase */                                                   \
+            in_reg[j] = conv_src_ptr(a, b, min(g, a.Cin - 1), HW)[pixoff];                              \
         }                                                                                               \
         _Pragma("unroll") for (int j = 0; j < W_PT; ++j) {                                              \
-            const int idx = tid + 256 * j;                                                              \
+            const int idx = min(tid + 256 * j, W4 - 1);                                                 \
             const int row = idx / (NT / 4), q = idx % (NT / 4);                                         \
-            w_reg[j] = (idx < W4)                                                                       \
-                ? *reinterpret_cast<const float4*>(wsrc + ((size_t)(C0) * TAPS + row) * a.CoutPad + q * 4) \
-                : make_float4(0.f, 0.f, 0.f, 0.f);                                                      \
+            w_reg[j] = *reinterpret_cast<const f32x4*>(wsrc + ((size_t)(C0) * TAPS + row) * a.CoutPad + q * 4); \
         }                                                                                               \
     }
-#define TCS_STORE_CHUNK()                                                                               \
+#define TCS_STORE_CHUNK(C0)                                                                             \
     {                                                                                                   \
         _Pragma("unroll") for (int j = 0; j < IN_PT; ++j)                                               \
-            if (in_active && sub + j * R < KC) s_in[(sub + j * R) * IN_CH + pos] = in_reg[j];           \
+            if (in_active && sub + j * R < KC)                                                          \
+                s_in[(sub + j * R) * IN_CH + pos] = (in_ok && (C0) + sub + j * R < a.Cin) ? in_reg[j] : 0.f; \
         _Pragma("unroll") for (int j = 0; j < W_PT; ++j) {                                              \
             const int idx = tid + 256 * j;                                                              \
-            if (idx < W4) *reinterpret_cast<float4*>(s_w + idx * 4) = w_reg[j];                         \
+            if (idx < W4) *reinterpret_cast<f32x4*>(s_w + idx * 4) = w_reg[j];                         \
         }                                                                                               \
     }
 
     // ---- K loop: global loads of chunk i+1 are in flight while the matrix cores work on chunk i ----
     const int cin_loop = (a.Cin + KC - 1) / KC * KC;
     TCS_LOAD_CHUNK(0)
-    TCS_STORE_CHUNK()
+    TCS_STORE_CHUNK(0)
     __syncthreads();
     for (int c0 = 0; c0 < cin_loop; c0 += KC) {
         const bool has_next = c0 + KC < cin_loop;
@@ -119,7 +111,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a) {
         }
         if (has_next) {
             __syncthreads();            // every wave has finished reading this chunk
-            TCS_STORE_CHUNK()           // (waits here for the prefetched registers)
+            TCS_STORE_CHUNK(c0 + KC)    // (waits here for the prefetched registers)
             __syncthreads();
         }
     }
@@ -132,14 +124,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a) {
     if (px >= W || py >= H) return;
     const size_t pix = (size_t)py * W + px;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int co = ct * NT + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-            if (co >= a.Cout) continue;
-            conv_epilogue<EPI>(a, b, co, pix, HW, acc[m][reg]);
-        }
-    }
+    for (int m = 0; m < MT; ++m) conv_epilogue_tile<EPI>(a, b, ct * NT + m * 32 + 4 * half, pix, HW, acc[m], 1.0f);
 }
 
 // Single-input-channel convolutions (BasicMotionEncoder.convf1 7x7, HiddenstateUpdater.convs.0 1x1):
@@ -243,7 +228,9 @@ int tcs_conv2d(const tcs_conv_desc* d, tcs_stream_t stream) {
     if (tot != d->Cin) return TCS_EINVAL;
     const int nt = cout_tile(d->Cout);
     a.w = d->weight; a.bias = d->bias;
-    a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.CoutPad = round_up(d->Cout, nt);
+    const int stride = d->stride == 2 ? 2 : 1;
+    a.Hin = d->H; a.Win = d->W;
+    a.B = d->B; a.H = stride == 2 ? (d->H - 1) / 2 + 1 : d->H; a.W = stride == 2 ? (d->W - 1) / 2 + 1 : d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.CoutPad = round_up(d->Cout, nt);
     a.act = d->act; a.post_scale = d->post_scale;
     a.add1 = d->addend; a.add2 = d->addend2; a.h = d->h; a.z = d->z;
     a.keep_z = d->blend_keep_z; a.hidden = 0;
@@ -258,15 +245,20 @@ int tcs_conv2d(const tcs_conv_desc* d, tcs_stream_t stream) {
         // fp16-split matrix-core path (tcs_conv_f16.hip); weights must come from tcs_pack_conv_weight_f16x3
         if (d->Cin == 1 || (d->ksize != 1 && d->ksize != 3)) return TCS_EUNSUPPORTED;
         if (d->epilogue == TCS_EPI_LINEAR && (d->out_ctot < d->out_coff + d->Cout || d->out_coff < 0)) return TCS_EINVAL;
-        if (d->epilogue != TCS_EPI_LINEAR && !d->h) return TCS_EINVAL;
+        const bool gru = d->epilogue == TCS_EPI_GRU_ZR || d->epilogue == TCS_EPI_GRU_Q;
+        if (gru && !d->h) return TCS_EINVAL;
         if (d->epilogue == TCS_EPI_GRU_ZR && (!d->out2 || (d->Cout & 1))) return TCS_EINVAL;
         if (d->epilogue == TCS_EPI_GRU_Q && !d->z) return TCS_EINVAL;
+        if (d->epilogue == TCS_EPI_DECONV2X && (d->Cout % 4 != 0 || stride != 1)) return TCS_EINVAL;
         a.hidden = d->epilogue == TCS_EPI_GRU_ZR ? d->Cout / 2 : (d->epilogue == TCS_EPI_GRU_Q ? d->Cout : 0);
+        if (d->epilogue == TCS_EPI_DECONV2X) a.hidden = d->Cout / 4;
         a.CoutPad = round_up(d->Cout, 32);
         a.w_unscale = d->weight_unscale;
-        return tcs_conv_f16x3_launch(a, d->ksize, d->epilogue, s);
+        a.npx = tcs_cdiv(a.W, 32);
+        return tcs_conv_f16x3_launch(a, d->ksize, d->epilogue, stride, s);
     }
     if (d->math != TCS_MATH_F32) return TCS_EINVAL;
+    if (stride != 1 || d->epilogue == TCS_EPI_DECONV2X) return TCS_EUNSUPPORTED;      // fp32 kernel: stride-1 'same' only
 
     if (d->epilogue == TCS_EPI_LINEAR) {
         if (d->out_ctot < d->out_coff + d->Cout || d->out_coff < 0) return TCS_EINVAL;

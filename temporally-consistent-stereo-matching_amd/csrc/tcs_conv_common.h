@@ -3,6 +3,7 @@
 #include "tcs_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvArgs {
     const float* src[TCS_MAX_SRC];
@@ -10,7 +11,8 @@ struct ConvArgs {
     int src_end[TCS_MAX_SRC];
     const float* w;
     const float* bias;
-    int B, H, W, Cin, Cout, CoutPad;
+    int B, H, W, Cin, Cout, CoutPad;   // H, W: OUTPUT grid of the kernel (= input grid for stride 1)
+    int Hin, Win;                      // input grid (stride-2 convolutions: H = (Hin-1)/2+1)
     int act;
     float post_scale;
     const float* add1;
@@ -22,6 +24,7 @@ struct ConvArgs {
     int out_ctot, out_coff;
     float* out2;
     int npx, npatch, nct;
+    int src_align8;         // every source boundary is a multiple of 8 channels (one source select per 8-channel group)
     float w_unscale;        // fp16-split kernel: 2^-s undoing the weight pre-scale (1 for the fp32 kernel)
 };
 
@@ -41,29 +44,105 @@ static inline int cout_tile(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64
 static inline int round_up(int a, int m) { return (a + m - 1) / m * m; }
 
 
-// One output element: bias, addends, activation / GRU gate arithmetic (update.py:81-85, 30-34, 62-66), store.
+// Source tensor of concatenated channel g (branch-free selects; g must be < Cin).
+__device__ __forceinline__ const float* conv_src_ptr(const ConvArgs& a, int b, int g, size_t HW) {
+    const float* sp = a.src[0];
+    int cb = 0, cs = a.src_ch[0];
+    const bool p1 = g >= a.src_end[0], p2 = g >= a.src_end[1], p3 = g >= a.src_end[2];
+    sp = p1 ? a.src[1] : sp; cb = p1 ? a.src_end[0] : cb; cs = p1 ? a.src_ch[1] : cs;
+    sp = p2 ? a.src[2] : sp; cb = p2 ? a.src_end[1] : cb; cs = p2 ? a.src_ch[2] : cs;
+    sp = p3 ? a.src[3] : sp; cb = p3 ? a.src_end[2] : cb; cs = p3 ? a.src_ch[3] : cs;
+    return sp + ((size_t)b * cs + (g - cb)) * HW;
+}
+
+// Epilogue of one 32(cout) x 32(pixel) accumulator tile: lane = pixel, the 16 registers walk output channels
+// co0 + (reg&3) + 8*(reg>>2).  Bias, addends, activation / GRU gate arithmetic (update.py:81-85, 30-34, 62-66).
+// Every load is unconditional on a clamped (always valid) index and the loads of the 16 registers are issued
+// together; only the stores are predicated.  (Per-element "load or zero" branches made hipcc wait for each
+// load in turn: 32 serial L2 round trips per lane.)
 template <int EPI>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, int b, int co, size_t pix, size_t HW, float acc) {
-    float v = acc + (a.bias ? a.bias[co] : 0.f);
+__device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, int b, int co0, size_t pix, size_t HW, const f32x16& acc,
+                                                   float scale) {
+    int cc[16];
+    bool ok[16];
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (r & 3) + 8 * (r >> 2);
+        ok[r] = co < a.Cout;
+        cc[r] = min(co, a.Cout - 1);
+        v[r] = acc[r] * scale;
+    }
+    if (a.bias) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += a.bias[cc[r]];
+    }
     if (EPI == TCS_EPI_LINEAR) {
-        if (a.add1) v += a.add1[((size_t)b * a.Cout + co) * HW + pix];
-        a.out[((size_t)b * a.out_ctot + a.out_coff + co) * HW + pix] = apply_act(v, a.act) * a.post_scale;
+        if (a.add1) {
+            float t[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = a.add1[((size_t)b * a.Cout + cc[r]) * HW + pix];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += t[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (ok[r]) a.out[((size_t)b * a.out_ctot + a.out_coff + cc[r]) * HW + pix] = apply_act(v[r], a.act) * a.post_scale;
     } else if (EPI == TCS_EPI_GRU_ZR) {
-        if (co < a.hidden) {
-            const size_t o = ((size_t)b * a.hidden + co) * HW + pix;
-            if (a.add1) v += a.add1[o];
-            a.out[o] = sigmoidf_(v);
-        } else {
-            const size_t o = ((size_t)b * a.hidden + (co - a.hidden)) * HW + pix;
-            if (a.add2) v += a.add2[o];
-            a.out2[o] = sigmoidf_(v) * a.h[o];
+        // channel < hidden: z = sigmoid(. + cz) -> out ; else r = sigmoid(. + cr), out2 = r * h
+        size_t o[16];
+        bool isz[16];
+        float ad[16], hh[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            isz[r] = cc[r] < a.hidden;
+            o[r] = ((size_t)b * a.hidden + (isz[r] ? cc[r] : cc[r] - a.hidden)) * HW + pix;
+        }
+        const bool any_add = a.add1 != nullptr || a.add2 != nullptr;
+        if (any_add) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* p = isz[r] ? a.add1 : a.add2;
+                ad[r] = p ? p[o[r]] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hh[r] = a.h[o[r]];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float g = sigmoidf_(v[r] + (any_add ? ad[r] : 0.f));
+            if (ok[r]) {
+                if (isz[r]) a.out[o[r]] = g;
+                else a.out2[o[r]] = g * hh[r];
+            }
+        }
+    } else if (EPI == TCS_EPI_DECONV2X) {
+        // ConvTranspose2d(4, stride 2, pad 1) computed as a 3x3 convolution with 4*C output channels (one group per
+        // output parity), pixel-shuffled on the way out: channel parity*C + c of pixel (i,j) -> out[c][2i+py][2j+px]
+        const int C = a.hidden, Wo = 2 * a.W;
+        const int i = (int)(pix / a.W), j = (int)(pix - (size_t)i * a.W);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int par = cc[r] / C, c = cc[r] - par * C;
+            if (ok[r]) a.out[(((size_t)b * C + c) * (2 * a.H) + 2 * i + (par >> 1)) * Wo + 2 * j + (par & 1)] = v[r];
         }
     } else {
-        const size_t o = ((size_t)b * a.hidden + co) * HW + pix;
-        if (a.add1) v += a.add1[o];
-        const float q = tanhf(v), zz = a.z[o], hh = a.h[o];
-        a.out[o] = a.keep_z ? zz * hh + (1.f - zz) * q : (1.f - zz) * hh + zz * q;
+        size_t o[16];
+        float ad[16], zz[16], hh[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = ((size_t)b * a.hidden + cc[r]) * HW + pix;
+        if (a.add1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ad[r] = a.add1[o[r]];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { zz[r] = a.z[o[r]]; hh[r] = a.h[o[r]]; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float q = tanhf(v[r] + (a.add1 ? ad[r] : 0.f));
+            if (ok[r]) a.out[o[r]] = a.keep_z ? zz[r] * hh[r] + (1.f - zz[r]) * q : (1.f - zz[r]) * hh[r] + zz[r] * q;
+        }
     }
 }
 
-int tcs_conv_f16x3_launch(ConvArgs& a, int ksize, int epilogue, hipStream_t s);   // tcs_conv_f16.hip
+int tcs_conv_f16x3_launch(ConvArgs& a, int ksize, int epilogue, int stride, hipStream_t s);   // tcs_conv_f16.hip

@@ -18,19 +18,36 @@
 // The weight image is produced once at pack time (tcs_pack_conv_weight_f16x3) in exactly this order,
 // so staging weights is a straight 16-byte-per-lane copy; activations are split on the fly.
 #include "tcs_conv_common.h"
+#include <stdlib.h>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
+typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));      // native vector: stays in registers (SROA)
+
 __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
-    x = fminf(fmaxf(x, -65504.f), 65504.f);
+    x = __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
     hi = (_Float16)x;
     lo = (_Float16)(x - (float)hi);
 }
 
-template <int KS, int MT, int KSTEPS, int EPI>
+// two values at a time: v_cvt_pk_f16_f32 (round-to-nearest-even, packed) halves the conversion work
+__device__ __forceinline__ void split_f16x2(float x0, float x1, half2_t& hi, half2_t& lo) {
+    float2_t v;
+    v[0] = __builtin_amdgcn_fmed3f(x0, -65504.f, 65504.f);
+    v[1] = __builtin_amdgcn_fmed3f(x1, -65504.f, 65504.f);
+    hi = __builtin_convertvector(v, half2_t);
+    const float2_t back = __builtin_convertvector(hi, float2_t);
+    lo = __builtin_convertvector(v - back, half2_t);
+}
+
+// MT = 32-wide output-channel tiles per wave, MP = patch rows per wave (block patch = 4*MP rows x 32 columns),
+// KSTEPS = 16-channel MFMA K-steps per LDS chunk.
+template <int KS, int MT, int MP, int KSTEPS, int EPI, int STRIDE = 1>
 __global__ __launch_bounds__(256) void k_conv_f16x3(ConvArgs a) {
-    constexpr int HALO = KS / 2, IH = 4 + KS - 1, IW = 32 + KS - 1, TAPS = KS * KS, IN_CH = IH * IW;
+    constexpr int HALO = KS / 2, PR = 4 * MP, IH = STRIDE * PR + KS - STRIDE, IW = STRIDE * 32 + KS - STRIDE, TAPS = KS * KS,
+                  IN_CH = IH * IW;
     constexpr int NT = 32 * MT, KC = 16 * KSTEPS, NG = 2 * KSTEPS;            // NG: 8-channel groups per chunk
     constexpr int IN_BYTES = NG * IN_CH * 16;                                  // one of {hi, lo}
     constexpr int W_UNITS = KSTEPS * TAPS * MT * 2 * 64;                       // 16-byte units per chunk
@@ -44,128 +61,170 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(ConvArgs a) {
     const int bid = blockIdx.x;
     const int ct = bid % a.nct, patch = bid / a.nct;
     const int b = blockIdx.y;
-    const int y0 = (patch / a.npx) * 4, x0 = (patch % a.npx) * 32;
-    const int H = a.H, W = a.W;
-    const size_t HW = (size_t)H * W;
+    const int y0 = (patch / a.npx) * PR, x0 = (patch % a.npx) * 32;
+    const int H = a.H, W = a.W;                     // output grid
+    const size_t HW = (size_t)H * W;                // output plane (epilogue)
+    const size_t HWi = (size_t)a.Hin * a.Win;       // input plane (staging)
 
-    f32x16 acc[MT];
+    f32x16 acc[MT][MP];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+        for (int p = 0; p < MP; ++p)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][p][i] = 0.f;
 
-    // ---- staging plan ---------------------------------------------------------------------------
-    // input: PARTS threads share one halo position; each converts GPT groups of 8 channels per chunk
-    constexpr int PARTS = (256 / IN_CH) >= 2 ? 2 : 1;                          // 3x3: 1 (204 positions), 1x1: 2 (128)
-    constexpr int GPT = NG / PARTS;                                            // groups per thread
-    static_assert(NG % PARTS == 0, "group split");
-    const int part = tid / IN_CH, pos = tid - part * IN_CH;
-    const bool in_active = part < PARTS;
-    const int sr = pos / IW, sc = pos - sr * IW;
-    const int gy = y0 - HALO + sr, gx = x0 - HALO + sc;
-    const bool in_ok = in_active && gy >= 0 && gy < H && gx >= 0 && gx < W;
-    const size_t pixoff = in_ok ? (size_t)gy * W + gx : 0;
+    // ---- staging plan -------------------------------------------------------------------------------
+    // A thread owns PPT halo positions and, for each, GPT of the chunk's NG 8-channel groups.  The group index
+    // is uniform across a wave (across the block when PARTS == 1), so the per-chunk base pointer of a group is
+    // computed on the scalar unit and every load is `global_load_dword v, v_pixel_offset, s[base]`.
+    constexpr int PARTS = (IN_CH <= 128) ? 2 : 1;             // 1x1 convs: two half-blocks split the groups
+    constexpr int TPP = 256 / PARTS;                          // threads per part
+    constexpr int PPT = (IN_CH + TPP - 1) / TPP;              // positions per thread
+    constexpr int GPT = NG / PARTS;                           // groups per thread
+    static_assert(NG % PARTS == 0, "groups must split evenly");
+    const int part = PARTS == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid / TPP);
+    const int tpos = tid - part * TPP;
+    int s_pix[PPT];                                           // pixel offset, -1 = zero padding, -2 = no slot
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int pos = tpos + TPP * k;
+        const int sr = pos / IW, sc = pos - sr * IW;
+        const int gy = STRIDE * y0 - HALO + sr, gx = STRIDE * x0 - HALO + sc;
+        s_pix[k] = pos >= IN_CH ? -2 : ((gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) ? gy * a.Win + gx : -1);
+    }
     constexpr int W_PT = (W_UNITS + 255) / 256;
-    // weights of this block: chunk stride in 16-byte units = TAPS * nct32 * 2 * 64 per k-step
     const int nct32 = a.CoutPad / 32;
-    const uint4* wsrc = reinterpret_cast<const uint4*>(a.w);
+    const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.w);
+    int w_off[W_PT];                                          // per-thread part of the weight unit index
+#pragma unroll
+    for (int j = 0; j < W_PT; ++j) {
+        const int u = min(tid + 256 * j, W_UNITS - 1);
+        const int piece = u / (MT * 128), within = u - piece * (MT * 128);     // piece = (kstep, tap)
+        w_off[j] = piece * nct32 * 128 + within;
+    }
+    const size_t w_chunk_units = (size_t)TAPS * nct32 * 128;                   // units per 16-channel k-step
+    const size_t w_ct = (size_t)ct * MT * 128;
 
-    float in_reg[GPT * 8];
-    uint4 w_reg[W_PT];
+    float in_reg[PPT * GPT * 8];
+    u32x4 w_reg[W_PT];
 
 #define TCS_LOAD_CHUNK(C0)                                                                                  \
     {                                                                                                       \
         _Pragma("unroll") for (int gi = 0; gi < GPT; ++gi) {                                                \
-            const int grp = part * GPT + gi;                                                                \
-            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                 \
-                const int g = (C0) + grp * 8 + j;                                                           \
-                float v = 0.f;                                                                              \
-                if (in_ok && g < a.Cin) {                                                                   \
-                    const float* sp = a.src[0];                                                             \
-                    int cb = 0, cs = a.src_ch[0];                                                           \
-                    if (g >= a.src_end[0]) { sp = a.src[1]; cb = a.src_end[0]; cs = a.src_ch[1]; }          \
-                    if (g >= a.src_end[1]) { sp = a.src[2]; cb = a.src_end[1]; cs = a.src_ch[2]; }          \
-                    if (g >= a.src_end[2]) { sp = a.src[3]; cb = a.src_end[2]; cs = a.src_ch[3]; }          \
-                    v = sp[((size_t)b * cs + (g - cb)) * HW + pixoff];                                      \
+            const int g0 = (C0) + (part * GPT + gi) * 8;                  /* wave-uniform */                \
+            if (a.src_align8) {                                                                             \
+                /* one scalar base pointer per group; loads are unconditional on clamped (valid) addresses and \
+                   zero-selected in TCS_STORE_CHUNK, so nothing waits for them before the MFMA phase */      \
+                const float* bj = conv_src_ptr(a, b, min(g0, a.Cin - 8), HWi);    /* scalar; +HWi per channel */ \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                             \
+                    _Pragma("unroll") for (int k = 0; k < PPT; ++k)                                         \
+                        in_reg[(k * GPT + gi) * 8 + j] = bj[max(s_pix[k], 0)];                              \
+                    bj += HWi;                                                                              \
                 }                                                                                           \
-                in_reg[gi * 8 + j] = v;                                                                     \
+            } else {                                                                                        \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                             \
+                    const float* base = conv_src_ptr(a, b, min(g0 + j, a.Cin - 1), HWi);                    \
+                    _Pragma("unroll") for (int k = 0; k < PPT; ++k)                                         \
+                        in_reg[(k * GPT + gi) * 8 + j] = base[max(s_pix[k], 0)];                            \
+                }                                                                                           \
             }                                                                                               \
         }                                                                                                   \
-        _Pragma("unroll") for (int j = 0; j < W_PT; ++j) {                                                  \
-            const int u = tid + 256 * j;                        /* unit index in the block's LDS image */   \
-            const int piece = u / (MT * 128), within = u - piece * (MT * 128);   /* piece = (kstep, tap) */ \
-            const int ks = piece / TAPS, t = piece - ks * TAPS;                                             \
-            const size_t gsrc = ((((size_t)((C0) / 16 + ks) * TAPS + t) * nct32 + (size_t)ct * MT) * 128) + within; \
-            w_reg[j] = (u < W_UNITS) ? wsrc[gsrc] : make_uint4(0, 0, 0, 0);                                 \
-        }                                                                                                   \
+        const u32x4* wchunk = wsrc + (size_t)((C0) / 16) * w_chunk_units + w_ct;      /* scalar */          \
+        _Pragma("unroll") for (int j = 0; j < W_PT; ++j) w_reg[j] = wchunk[w_off[j]];                       \
     }
-#define TCS_STORE_CHUNK()                                                                                   \
+#define TCS_STORE_CHUNK(C0)                                                                                 \
     {                                                                                                       \
-        if (in_active) {                                                                                    \
-            _Pragma("unroll") for (int gi = 0; gi < GPT; ++gi) {                                            \
-                const int grp = part * GPT + gi;                                                            \
-                half8 hi8, lo8;                                                                             \
-                _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                             \
-                    _Float16 h_, l_;                                                                        \
-                    split_f16(in_reg[gi * 8 + j], h_, l_);                                                  \
-                    hi8[j] = h_; lo8[j] = l_;                                                               \
+        _Pragma("unroll") for (int k = 0; k < PPT; ++k) {                                                   \
+            if (s_pix[k] > -2) {                                                                            \
+                const bool pix_ok = s_pix[k] >= 0;                                                          \
+                _Pragma("unroll") for (int gi = 0; gi < GPT; ++gi) {                                        \
+                    const int grp = part * GPT + gi;                                                        \
+                    const int gq = (C0) + grp * 8;                                                          \
+                    half8 hi8, lo8;                                                                         \
+                    _Pragma("unroll") for (int j = 0; j < 8; j += 2) {                                      \
+                        half2_t h2, l2;                                                                     \
+                        const float x0_ = (pix_ok && gq + j < a.Cin) ? in_reg[(k * GPT + gi) * 8 + j] : 0.f;        \
+                        const float x1_ = (pix_ok && gq + j + 1 < a.Cin) ? in_reg[(k * GPT + gi) * 8 + j + 1] : 0.f; \
+                        split_f16x2(x0_, x1_, h2, l2);                                                      \
+                        hi8[j] = h2[0]; hi8[j + 1] = h2[1]; lo8[j] = l2[0]; lo8[j + 1] = l2[1];             \
+                    }                                                                                       \
+                    const size_t unit = (size_t)grp * IN_CH + tpos + TPP * k;                               \
+                    *reinterpret_cast<half8*>(s_in_hi + unit * 16) = hi8;                                   \
+                    *reinterpret_cast<half8*>(s_in_lo + unit * 16) = lo8;                                   \
                 }                                                                                           \
-                *reinterpret_cast<half8*>(s_in_hi + ((size_t)grp * IN_CH + pos) * 16) = hi8;                \
-                *reinterpret_cast<half8*>(s_in_lo + ((size_t)grp * IN_CH + pos) * 16) = lo8;                \
             }                                                                                               \
         }                                                                                                   \
         _Pragma("unroll") for (int j = 0; j < W_PT; ++j) {                                                  \
             const int u = tid + 256 * j;                                                                    \
-            if (u < W_UNITS) *reinterpret_cast<uint4*>(s_w + (size_t)u * 16) = w_reg[j];                    \
+            if (u < W_UNITS) *reinterpret_cast<u32x4*>(s_w + (size_t)u * 16) = w_reg[j];                    \
         }                                                                                                   \
     }
 
+    // operand fetch of one (k-step, tap): MP input fragments + MT weight fragments, hi and lo, one ds_read_b128 each
+    struct Frag { half8 b_hi[MP], b_lo[MP], a_hi[MT], a_lo[MT]; };
+#define TCS_FETCH(F, KSI, T)                                                                                \
+    {                                                                                                       \
+        const int dy_ = (T) / KS, dx_ = (T) % KS;                                                           \
+        _Pragma("unroll") for (int p = 0; p < MP; ++p) {                                                    \
+            const size_t boff = ((size_t)(2 * (KSI) + half) * IN_CH + (STRIDE * (wave * MP + p) + dy_) * IW + dx_ + STRIDE * l31) * 16; \
+            F.b_hi[p] = *reinterpret_cast<const half8*>(s_in_hi + boff);                                    \
+            F.b_lo[p] = *reinterpret_cast<const half8*>(s_in_lo + boff);                                    \
+        }                                                                                                   \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                    \
+            const unsigned char* wt = s_w + ((size_t)(((KSI) * TAPS + (T)) * MT + m) * 128 + lane) * 16;    \
+            F.a_hi[m] = *reinterpret_cast<const half8*>(wt);                                                \
+            F.a_lo[m] = *reinterpret_cast<const half8*>(wt + 1024);                                         \
+        }                                                                                                   \
+    }
+#define TCS_MMA(F)                                                                                          \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                          \
+        _Pragma("unroll") for (int p = 0; p < MP; ++p) {                                                    \
+            acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_lo[m], F.b_hi[p], acc[m][p], 0, 0, 0);   \
+            acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_hi[m], F.b_lo[p], acc[m][p], 0, 0, 0);   \
+            acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_hi[m], F.b_hi[p], acc[m][p], 0, 0, 0);   \
+        }
+
     const int cin_loop = (a.Cin + KC - 1) / KC * KC;
     TCS_LOAD_CHUNK(0)
-    TCS_STORE_CHUNK()
+    TCS_STORE_CHUNK(0)
     __syncthreads();
     for (int c0 = 0; c0 < cin_loop; c0 += KC) {
         const bool has_next = c0 + KC < cin_loop;
         if (has_next) TCS_LOAD_CHUNK(c0 + KC)
+        // software pipeline over the KSTEPS*TAPS steps: the ds_reads of step i+1 are in flight during the MFMAs of step i
+        constexpr int NSTEP = KSTEPS * TAPS;
+        Frag f0, f1;
+        TCS_FETCH(f0, 0, 0)
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-#pragma unroll
-            for (int t = 0; t < TAPS; ++t) {
-                const int dy = t / KS, dx = t % KS;
-                const size_t boff = ((size_t)(2 * ks + half) * IN_CH + (wave + dy) * IW + dx + l31) * 16;
-                const half8 b_hi = *reinterpret_cast<const half8*>(s_in_hi + boff);
-                const half8 b_lo = *reinterpret_cast<const half8*>(s_in_lo + boff);
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const unsigned char* wt = s_w + ((size_t)((ks * TAPS + t) * MT + m) * 128 + lane) * 16;
-                    const half8 a_hi = *reinterpret_cast<const half8*>(wt);
-                    const half8 a_lo = *reinterpret_cast<const half8*>(wt + 1024);
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc[m], 0, 0, 0);
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc[m], 0, 0, 0);
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc[m], 0, 0, 0);
-                }
+        for (int i = 0; i < NSTEP; i += 2) {
+            if (i + 1 < NSTEP) TCS_FETCH(f1, (i + 1) / TAPS, (i + 1) % TAPS)
+            TCS_MMA(f0)
+            if (i + 1 < NSTEP) {
+                if (i + 2 < NSTEP) TCS_FETCH(f0, (i + 2) / TAPS, (i + 2) % TAPS)
+                TCS_MMA(f1)
             }
         }
         if (has_next) {
             __syncthreads();
-            TCS_STORE_CHUNK()
+            TCS_STORE_CHUNK(c0 + KC)
             __syncthreads();
         }
     }
 #undef TCS_LOAD_CHUNK
 #undef TCS_STORE_CHUNK
+#undef TCS_FETCH
+#undef TCS_MMA
 
-    const int px = x0 + l31, py = y0 + wave;
-    if (px >= W || py >= H) return;
-    const size_t pix = (size_t)py * W + px;
+    const int px = x0 + l31;
+    if (px >= W) return;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
+    for (int p = 0; p < MP; ++p) {
+        const int py = y0 + wave * MP + p;
+        if (py >= H) continue;
+        const size_t pix = (size_t)py * W + px;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int co = ct * NT + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-            if (co >= a.Cout) continue;
-            conv_epilogue<EPI>(a, b, co, pix, HW, acc[m][reg] * a.w_unscale);
-        }
+        for (int m = 0; m < MT; ++m) conv_epilogue_tile<EPI>(a, b, ct * NT + m * 32 + 4 * half, pix, HW, acc[m][p], a.w_unscale);
     }
 }
 
@@ -195,36 +254,69 @@ __global__ __launch_bounds__(256) void k_pack_weight_f16x3(const float* __restri
     packed[u] = *reinterpret_cast<uint4*>(&v);
 }
 
-template <int KS, int MT, int KSTEPS, int EPI>
-static int launch_f16(const ConvArgs& a, hipStream_t s) {
-    constexpr int IH = 4 + KS - 1, IW = 32 + KS - 1, TAPS = KS * KS;
+template <int KS, int MT, int MP, int KSTEPS, int EPI, int STRIDE = 1>
+static int launch_f16(ConvArgs& a, hipStream_t s) {
+    constexpr int IH = STRIDE * 4 * MP + KS - STRIDE, IW = STRIDE * 32 + KS - STRIDE, TAPS = KS * KS;
     const size_t lds = (size_t)2 * (2 * KSTEPS) * IH * IW * 16 + (size_t)KSTEPS * TAPS * MT * 2 * 1024;
-    auto kern = k_conv_f16x3<KS, MT, KSTEPS, EPI>;
+    auto kern = k_conv_f16x3<KS, MT, MP, KSTEPS, EPI, STRIDE>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return TCS_ELAUNCH;
     }
+    a.npatch = a.npx * tcs_cdiv(a.H, 4 * MP);
+    a.nct = (a.CoutPad / 32) / MT;
     hipLaunchKernelGGL(kern, dim3(a.npatch * a.nct, a.B), dim3(256), lds, s, a);
     return tcs_launch_status();
 }
 
-template <int KS, int KSTEPS, int EPI>
+// tuning knobs (read once): TCS_F16_MT / TCS_F16_MP in {1,2}, TCS_F16_KSTEPS in {1,2}; 0 = heuristic
+static int env_int(const char* name) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : 0;
+}
+
+template <int KS, int EPI>
 static int launch_f16_tile(ConvArgs& a, hipStream_t s) {
-    // 64 output channels per block when that still leaves >= 2 blocks per CU, else 32 (small maps)
+    static const int force_mt = env_int("TCS_F16_MT"), force_mp = env_int("TCS_F16_MP"), force_ks = env_int("TCS_F16_KSTEPS");
     const int nct32 = a.CoutPad / 32;
-    int mt = (nct32 % 2 == 0 && (long long)a.npatch * a.B * (nct32 / 2) >= 512) ? 2 : 1;
-    a.nct = nct32 / mt;
-    return mt == 2 ? launch_f16<KS, 2, KSTEPS, EPI>(a, s) : launch_f16<KS, 1, KSTEPS, EPI>(a, s);
+    const long long px_tiles = (long long)a.npx * tcs_cdiv(a.H, 4) * a.B;           // 128-pixel patches
+    // widest tile (most register reuse of LDS operands) that still leaves >= 2 blocks per CU
+    int mt = (nct32 % 2 == 0 && px_tiles * (nct32 / 2) >= 512) ? 2 : 1;
+    int mp = 1;
+    if (force_mt) mt = (force_mt == 2 && nct32 % 2 == 0) ? 2 : 1;
+    if (force_mp) mp = force_mp == 2 ? 2 : 1;
+    if (KS == 1) {
+        if (mt == 2) return mp == 2 ? launch_f16<1, 2, 2, 4, EPI>(a, s) : launch_f16<1, 2, 1, 4, EPI>(a, s);
+        return mp == 2 ? launch_f16<1, 1, 2, 4, EPI>(a, s) : launch_f16<1, 1, 1, 4, EPI>(a, s);
+    }
+    const int ks = force_ks == 2 ? 2 : 1;
+    if (ks == 2) {
+        if (mt == 2) return mp == 2 ? launch_f16<3, 2, 2, 2, EPI>(a, s) : launch_f16<3, 2, 1, 2, EPI>(a, s);
+        return mp == 2 ? launch_f16<3, 1, 2, 2, EPI>(a, s) : launch_f16<3, 1, 1, 2, EPI>(a, s);
+    }
+    if (mt == 2) return mp == 2 ? launch_f16<3, 2, 2, 1, EPI>(a, s) : launch_f16<3, 2, 1, 1, EPI>(a, s);
+    return mp == 2 ? launch_f16<3, 1, 2, 1, EPI>(a, s) : launch_f16<3, 1, 1, 1, EPI>(a, s);
 }
 
 template <int EPI>
 static int launch_f16_ks(ConvArgs& a, int ksize, hipStream_t s) {
-    if (ksize == 3) return launch_f16_tile<3, 1, EPI>(a, s);
-    if (ksize == 1) return launch_f16_tile<1, 4, EPI>(a, s);
+    if (ksize == 3) return launch_f16_tile<3, EPI>(a, s);
+    if (ksize == 1) return launch_f16_tile<1, EPI>(a, s);
     return TCS_EUNSUPPORTED;
 }
 
-int tcs_conv_f16x3_launch(ConvArgs& a, int ksize, int epilogue, hipStream_t s) {
+int tcs_conv_f16x3_launch(ConvArgs& a, int ksize, int epilogue, int stride, hipStream_t s) {
+    a.src_align8 = (a.Cin % 8 == 0) ? 1 : 0;
+    for (int i = 0; i < TCS_MAX_SRC; ++i)
+        if (a.src_end[i] != 0x7fffffff && (a.src_end[i] % 8) != 0) a.src_align8 = 0;
+    if (stride == 2) {                       // 3x3 stride-2 pad-1 (conv_4_8 / conv_8_16 of the U-Nets), linear epilogue
+        if (ksize != 3 || epilogue != TCS_EPI_LINEAR) return TCS_EUNSUPPORTED;
+        return launch_f16<3, 1, 1, 1, TCS_EPI_LINEAR, 2>(a, s);
+    }
+    if (epilogue == TCS_EPI_DECONV2X) {
+        if (ksize != 3) return TCS_EUNSUPPORTED;
+        return launch_f16<3, 1, 1, 1, TCS_EPI_DECONV2X, 1>(a, s);
+    }
     switch (epilogue) {
         case TCS_EPI_LINEAR: return launch_f16_ks<TCS_EPI_LINEAR>(a, ksize, s);
         case TCS_EPI_GRU_ZR: return launch_f16_ks<TCS_EPI_GRU_ZR>(a, ksize, s);
@@ -233,7 +325,72 @@ int tcs_conv_f16x3_launch(ConvArgs& a, int ksize, int epilogue, hipStream_t s) {
     }
 }
 
+extern "C" size_t tcs_conv_packed_floats_f16x3(int Cout, int Cin, int ksize);
+extern "C" int tcs_pack_conv_weight_f16x3(const float* w_oihw, int Cout, int Cin, int ksize, int scale_log2, float* packed,
+                                          tcs_stream_t stream);
+
+// ConvTranspose2d(4,2,1) weights [Cin][Cout][4][4] -> equivalent 3x3 conv weights [4*Cout][Cin][3][3]:
+// output parity (py,px), tap offset (dy,dx) in {-1,0,1}: ky = py ? (dy == 1 ? 0 : 2) : (dy == 0 ? 1 : 3), valid when
+// (py == 0 and dy in {0,-1}) or (py == 1 and dy in {+1,0}); same along x.
+__global__ __launch_bounds__(256) void k_deconv_to_conv(const float* __restrict__ wt, int Cin, int Cout, float* __restrict__ w3) {
+    const size_t n = (size_t)4 * Cout * Cin * 9;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int tap = (int)(i % 9), ci = (int)((i / 9) % Cin);
+    const int oc = (int)(i / ((size_t)9 * Cin));
+    const int par = oc / Cout, co = oc - par * Cout, py = par >> 1, px = par & 1;
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    int ky = -1, kx = -1;
+    if (py == 0) ky = dy == 0 ? 1 : (dy == -1 ? 3 : -1); else ky = dy == 1 ? 0 : (dy == 0 ? 2 : -1);
+    if (px == 0) kx = dx == 0 ? 1 : (dx == -1 ? 3 : -1); else kx = dx == 1 ? 0 : (dx == 0 ? 2 : -1);
+    w3[i] = (ky >= 0 && kx >= 0) ? wt[(((size_t)ci * Cout + co) * 4 + ky) * 4 + kx] : 0.f;
+}
+
+// InstanceNorm2d (affine=False): one block per (b, c) plane; two passes over the plane (it lives in L2).
+__global__ __launch_bounds__(256) void k_instance_norm(const float* __restrict__ x, int HW, float eps, int act,
+                                                       const float* __restrict__ addend, float* __restrict__ out) {
+    __shared__ float red[8];
+    const float* p = x + (size_t)blockIdx.x * HW;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) s += p[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)HW;
+    float v = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) { const float d = p[i] - mean; v = fmaf(d, d, v); }
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = v;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf(((red[4] + red[5]) + (red[6] + red[7])) / (float)HW + eps);
+    const float* ad = addend ? addend + (size_t)blockIdx.x * HW : nullptr;
+    float* o = out + (size_t)blockIdx.x * HW;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const float y = apply_act((p[i] - mean) * rstd, act);
+        o[i] = ad ? y + ad[i] : y;
+    }
+}
+
 extern "C" {
+
+size_t tcs_deconv_packed_floats_f16x3(int Cin, int Cout) { return tcs_conv_packed_floats_f16x3(4 * Cout, Cin, 3); }
+
+int tcs_pack_deconv4x4s2_f16x3(const float* w_iohw, int Cin, int Cout, int scale_log2, float* packed, float* scratch_oihw,
+                               tcs_stream_t stream) {
+    if (!w_iohw || !packed || !scratch_oihw || Cin <= 0 || Cout <= 0) return TCS_EINVAL;
+    const size_t n = (size_t)4 * Cout * Cin * 9;
+    hipLaunchKernelGGL(k_deconv_to_conv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tcs_stream(stream), w_iohw, Cin, Cout,
+                       scratch_oihw);
+    return tcs_pack_conv_weight_f16x3(scratch_oihw, 4 * Cout, Cin, 3, scale_log2, packed, stream);
+}
+
+int tcs_instance_norm(const float* x, int B, int C, int H, int W, float eps, int act, const float* addend, float* out,
+                      tcs_stream_t stream) {
+    if (!x || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0 || eps < 0.f) return TCS_EINVAL;
+    hipLaunchKernelGGL(k_instance_norm, dim3((unsigned)((size_t)B * C)), dim3(256), 0, tcs_stream(stream), x, H * W, eps, act,
+                       addend, out);
+    return tcs_launch_status();
+}
 
 size_t tcs_conv_packed_floats_f16x3(int Cout, int Cin, int ksize) {
     if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return 0;

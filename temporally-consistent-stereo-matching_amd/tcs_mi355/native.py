@@ -34,7 +34,7 @@ class ConvDesc(C.Structure):
         ("addend", c_fp), ("addend2", c_fp), ("h", c_fp), ("z", c_fp),
         ("blend_keep_z", c_int),
         ("out", c_fp), ("out_ctot", c_int), ("out_coff", c_int), ("out2", c_fp),
-        ("math", c_int), ("weight_unscale", c_f),
+        ("stride", c_int), ("math", c_int), ("weight_unscale", c_f),
     ]
 
 
@@ -70,6 +70,9 @@ SIGNATURES = {
     "tcs_pack_conv_weight": (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_fp]),
     "tcs_conv_packed_floats_f16x3": (c_sz, [c_int, c_int, c_int]),
     "tcs_pack_conv_weight_f16x3": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp]),
+    "tcs_deconv_packed_floats_f16x3": (c_sz, [c_int, c_int]),
+    "tcs_pack_deconv4x4s2_f16x3": (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp]),
+    "tcs_instance_norm": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_f, c_int, c_fp, c_fp, c_fp]),
     "tcs_conv2d": (c_int, [C.POINTER(ConvDesc), c_fp]),
 }
 

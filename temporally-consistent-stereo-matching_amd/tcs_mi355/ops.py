@@ -324,6 +324,47 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], math: str = "f
     return PackedConv(packed, b, cout, cin, kh)
 
 
+def pack_deconv4x4s2(weight: torch.Tensor) -> PackedConv:
+    """nn.ConvTranspose2d(Cin, Cout, 4, stride=2, padding=1, bias=False) -> the fp16-split layout of the equivalent
+    3x3 convolution with 4*Cout parity-grouped outputs (tcs_pack_deconv4x4s2_f16x3); use with `deconv4x4s2`."""
+    cin, cout, kh, kw = (int(s) for s in weight.shape)
+    if (kh, kw) != (4, 4):
+        raise ValueError("4x4 transposed convolutions only")
+    L = nv.lib()
+    w = weight.detach().float().contiguous()
+    wmax = float(w.abs().max())
+    s_log2 = 0 if wmax == 0.0 else max(-40, min(40, int(12 - math_floor_log2(wmax))))
+    packed = torch.empty(L.tcs_deconv_packed_floats_f16x3(cin, cout), dtype=torch.float32, device=w.device)
+    scratch = torch.empty(4 * cout * cin * 9, dtype=torch.float32, device=w.device)
+    nv.check(L.tcs_pack_deconv4x4s2_f16x3(nv.ptr(w, "weight"), cin, cout, s_log2, nv.ptr(packed), nv.ptr(scratch), nv.stream()),
+             "tcs_pack_deconv4x4s2_f16x3")
+    return PackedConv(packed, None, 4 * cout, cin, 3, MATH_F16X3, 2.0 ** (-s_log2))
+
+
+def deconv4x4s2(pc: PackedConv, srcs: Sequence[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[B,Cin,H,W] -> [B,Cout,2H,2W] (ConvTranspose2d k=4, s=2, p=1, no bias)."""
+    d = _desc(pc, srcs)
+    cout = pc.cout // 4
+    if out is None:
+        out = _new(srcs[0], d.B, cout, 2 * d.H, 2 * d.W)
+    d.epilogue, d.act = 3, 0
+    d.out, d.out_ctot, d.out_coff = nv.ptr(out, "out"), cout, 0
+    nv.check(nv.lib().tcs_conv2d(C.byref(d), nv.stream()), "tcs_conv2d[deconv2x]")
+    return out
+
+
+def instance_norm(x: torch.Tensor, act: str = "none", addend: Optional[torch.Tensor] = None, eps: float = 1e-5,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(InstanceNorm2d(x)) + addend (affine=False, biased variance)."""
+    B, Cc, H, W = _dims4(x, "x")
+    if addend is not None and tuple(addend.shape) != (B, Cc, H, W):
+        raise ValueError("instance_norm: bad addend shape")
+    out = torch.empty_like(x) if out is None else out
+    nv.check(nv.lib().tcs_instance_norm(nv.ptr(x, "x"), B, Cc, H, W, float(eps), ACT[act], nv.ptr(addend, "addend"), nv.ptr(out),
+                                        nv.stream()), "tcs_instance_norm")
+    return out
+
+
 def math_floor_log2(x: float) -> int:
     import math as _m
     return int(_m.floor(_m.log2(x)))
@@ -354,13 +395,19 @@ def _desc(pc: PackedConv, srcs: Sequence[torch.Tensor]) -> nv.ConvDesc:
 
 
 def conv2d(pc: PackedConv, srcs: Sequence[torch.Tensor], act: str = "none", addend=None, post_scale: float = 1.0,
-           out: Optional[torch.Tensor] = None, out_coff: int = 0) -> torch.Tensor:
+           out: Optional[torch.Tensor] = None, out_coff: int = 0, stride: int = 1) -> torch.Tensor:
     d = _desc(pc, srcs)
+    if stride not in (1, 2):
+        raise ValueError("stride 1 or 2")
+    if stride == 2 and (pc.math != MATH_F16X3 or pc.ksize != 3):
+        raise NotImplementedError("stride-2 convolutions run on the fp16-split kernel (3x3 only)")
+    Ho, Wo = ((d.H - 1) // 2 + 1, (d.W - 1) // 2 + 1) if stride == 2 else (d.H, d.W)
+    d.stride = stride
     if out is None:
-        out = _new(srcs[0], d.B, pc.cout, d.H, d.W)
-    if out.shape[0] != d.B or tuple(out.shape[2:]) != (d.H, d.W):
+        out = _new(srcs[0], d.B, pc.cout, Ho, Wo)
+    if out.shape[0] != d.B or tuple(out.shape[2:]) != (Ho, Wo):
         raise ValueError("conv2d: bad `out` shape")
-    if addend is not None and tuple(addend.shape) != (d.B, pc.cout, d.H, d.W):
+    if addend is not None and tuple(addend.shape) != (d.B, pc.cout, Ho, Wo):
         raise ValueError("conv2d: bad addend shape")
     d.epilogue, d.act, d.post_scale = EPI_LINEAR, ACT[act], float(post_scale)
     d.addend = nv.ptr(addend, "addend")

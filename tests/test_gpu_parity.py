@@ -412,3 +412,30 @@ def test_graph_replay_full_size_many_frames(dev, model):
         run_sequence(model, seq, iters=2, device=dev, collect=graphed)
         for t in range(4):
             assert epe(graphed[t], eager[t]) <= 1e-5, (rep, t)
+
+
+def test_stride2_deconv_instancenorm_vs_torch(dev):
+    """The U-Net pieces moved off MIOpen: 3x3 stride-2 conv, ConvTranspose2d(4,2,1), InstanceNorm (+act, +addend)."""
+    from tcs_mi355 import ops
+    gen = torch.Generator().manual_seed(21)
+    for (cin, cout, H, W) in ((64, 96, 120, 160), (96, 128, 60, 80), (40, 33, 9, 21)):
+        x = torch.randn(1, cin, H, W, generator=gen)
+        w = torch.randn(cout, cin, 3, 3, generator=gen) * (2.0 / (9 * cin)) ** 0.5
+        b = torch.randn(cout, generator=gen) * 0.1
+        ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1))
+        got = ops.conv2d(ops.pack_conv(D(w, dev), D(b, dev), "f16x3"), [D(x, dev)], act="relu", stride=2)
+        assert tuple(got.shape) == tuple(ref.shape)
+        assert maxdiff(got, ref) <= 2e-5, (cin, cout, H, W)
+    for (cin, cout, H, W) in ((128, 96, 30, 40), (96, 64, 60, 80), (24, 10, 5, 7)):
+        x = torch.randn(2, cin, H, W, generator=gen)
+        wt = torch.randn(cin, cout, 4, 4, generator=gen) * (2.0 / (16 * cin)) ** 0.5
+        ref = F.conv_transpose2d(x.double(), wt.double(), None, stride=2, padding=1)
+        got = ops.deconv4x4s2(ops.pack_deconv4x4s2(D(wt, dev)), [D(x, dev)])
+        assert tuple(got.shape) == (2, cout, 2 * H, 2 * W)
+        assert maxdiff(got, ref) <= 2e-5, (cin, cout, H, W)
+    x = torch.randn(2, 7, 33, 45, generator=gen) * 3 + 1
+    add = torch.randn(2, 7, 33, 45, generator=gen)
+    assert maxdiff(ops.instance_norm(D(x, dev)), F.instance_norm(x.double())) <= 1e-5
+    assert maxdiff(ops.instance_norm(D(x, dev), act="leaky", addend=D(add, dev)),
+                   F.leaky_relu(F.instance_norm(x.double()), 0.01) + add.double()) <= 1e-5
+    assert maxdiff(ops.instance_norm(D(x, dev), act="relu"), F.relu(F.instance_norm(x.double()))) <= 1e-5
