@@ -242,6 +242,10 @@ int tcs_pack_deconv4x4s2_f16x3(const float* w_iohw, int Cin, int Cout, int scale
  * out = act((x - mean) / sqrt(var + eps)) + addend      (basic_layers.py:28-35,65-76; update.py:325-367) */
 int tcs_instance_norm(const float* x, int B, int C, int H, int W, float eps, int act, const float* addend, float* out,
                       tcs_stream_t stream);
+/* nn.Conv2d(Cin, 1, 3, padding=1): single-output-channel 3x3 convolution as a plain fp32 reduction (FlowHead.conv2,
+ * core/update.py:13).  w_oihw is the ORIGINAL [1,Cin,3,3] weight (no packing); out [B,1,H,W]. */
+int tcs_conv3x3_cout1(const float* x, const float* w_oihw, const float* bias, int B, int Cin, int H, int W, float* out,
+                      tcs_stream_t stream);
 /* nn.Conv2d(k, padding=k/2) + fused epilogue; covers ConvGRU / Lightfuse / HiddenstateUpdater /
  * BasicMotionEncoder / FlowHead / the stride-1 convs of DispRefine and DispGradPredictor (core/update.py). */
 int tcs_conv2d(const tcs_conv_desc* desc, tcs_stream_t stream);

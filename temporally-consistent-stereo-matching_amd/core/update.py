@@ -167,7 +167,10 @@ class FlowHead(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        return hip_conv(self.conv2, [hip_conv(self.conv1, [x], act="relu")])
+        y = hip_conv(self.conv1, [x], act="relu")
+        if self.conv2.out_channels == 1:
+            return ops.conv3x3_cout1(y, self.conv2.weight, self.conv2.bias)      # 256 -> 1: reduction kernel, not a 32-wide MFMA tile
+        return hip_conv(self.conv2, [y])
 
 
 class BasicMotionEncoder(nn.Module):

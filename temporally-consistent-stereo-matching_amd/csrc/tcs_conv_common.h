@@ -44,15 +44,27 @@ static inline int cout_tile(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64
 static inline int round_up(int a, int m) { return (a + m - 1) / m * m; }
 
 
+// Pointers selected among kernel arguments lose their address space (hipcc then emits flat_load + conservative
+// s_waitcnt vmcnt(0) between loads, which serialised the staging loads at full memory latency).  Casting back to the
+// global address space gives global_load_dword with an SGPR base.
+typedef const __attribute__((address_space(1))) float* gptr_t;
+
+// base (SGPR pair) + 32-bit unsigned byte offset (VGPR): selects the `global_load v, v_off, s[base]` addressing form,
+// which needs no per-load 64-bit VGPR address (those temporaries made hipcc emit s_waitcnt vmcnt(0) between loads).
+typedef const __attribute__((address_space(1))) char* gbytes_t;
+__device__ __forceinline__ float gload_f32(gptr_t base, unsigned byte_off) {
+    return *reinterpret_cast<gptr_t>(reinterpret_cast<gbytes_t>(base) + byte_off);
+}
+
 // Source tensor of concatenated channel g (branch-free selects; g must be < Cin).
-__device__ __forceinline__ const float* conv_src_ptr(const ConvArgs& a, int b, int g, size_t HW) {
+__device__ __forceinline__ gptr_t conv_src_ptr(const ConvArgs& a, int b, int g, size_t HW) {
     const float* sp = a.src[0];
     int cb = 0, cs = a.src_ch[0];
     const bool p1 = g >= a.src_end[0], p2 = g >= a.src_end[1], p3 = g >= a.src_end[2];
     sp = p1 ? a.src[1] : sp; cb = p1 ? a.src_end[0] : cb; cs = p1 ? a.src_ch[1] : cs;
     sp = p2 ? a.src[2] : sp; cb = p2 ? a.src_end[1] : cb; cs = p2 ? a.src_ch[2] : cs;
     sp = p3 ? a.src[3] : sp; cb = p3 ? a.src_end[2] : cb; cs = p3 ? a.src_ch[3] : cs;
-    return sp + ((size_t)b * cs + (g - cb)) * HW;
+    return (gptr_t)(sp + ((size_t)b * cs + (g - cb)) * HW);
 }
 
 // Epilogue of one 32(cout) x 32(pixel) accumulator tile: lane = pixel, the 16 registers walk output channels

@@ -20,6 +20,12 @@
 #include "tcs_conv_common.h"
 #include <stdlib.h>
 
+#ifdef TCS_CONV_STAMPS
+// Diagnostic build only (lib/libtcs_mi355_stamps.so): per-phase shader-clock sums of the K loop, per wave.
+__device__ unsigned long long tcs_conv_stamps[8 * 16384];
+#define TCS_STAMP(T) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(T) :: "memory"); }
+#endif
+
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
@@ -44,7 +50,7 @@ __device__ __forceinline__ void split_f16x2(float x0, float x1, half2_t& hi, hal
 
 // MT = 32-wide output-channel tiles per wave, MP = patch rows per wave (block patch = 4*MP rows x 32 columns),
 // KSTEPS = 16-channel MFMA K-steps per LDS chunk.
-template <int KS, int MT, int MP, int KSTEPS, int EPI, int STRIDE = 1>
+template <int KS, int MT, int MP, int KSTEPS, int EPI, int STRIDE = 1, int PF = 1>
 __global__ __launch_bounds__(256) void k_conv_f16x3(ConvArgs a) {
     constexpr int HALO = KS / 2, PR = 4 * MP, IH = STRIDE * PR + KS - STRIDE, IW = STRIDE * 32 + KS - STRIDE, TAPS = KS * KS,
                   IN_CH = IH * IW;
@@ -106,17 +112,31 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(ConvArgs a) {
     const size_t w_chunk_units = (size_t)TAPS * nct32 * 128;                   // units per 16-channel k-step
     const size_t w_ct = (size_t)ct * MT * 128;
 
-    float in_reg[PPT * GPT * 8];
-    u32x4 w_reg[W_PT];
+    // PF = prefetch distance in chunks: PF register sets hold chunks in flight (set B only exists when PF == 2)
+    float in_regA[PPT * GPT * 8], in_regB[PF == 2 ? PPT * GPT * 8 : 1];
+    u32x4 w_regA[W_PT], w_regB[PF == 2 ? W_PT : 1];
 
-#define TCS_LOAD_CHUNK(C0)                                                                                  \
+    // Per-group scalar base pointers of the NEXT chunk to be loaded.  They are computed one phase ahead of their use
+    // (right after the previous TCS_LOAD_CHUNK), so the scalar kernarg loads behind conv_src_ptr() land during the MFMA
+    // phase instead of stalling the load issue (measured: 2.1k of 5.7k cycles per chunk before this).
+    gptr_t nbase[GPT];
+#define TCS_GROUP_BASES(C0)                                                                                 \
+    _Pragma("unroll") for (int gi = 0; gi < GPT; ++gi)                                                      \
+        nbase[gi] = conv_src_ptr(a, b, min((C0) + (part * GPT + gi) * 8, max(a.Cin - 8, 0)), HWi);
+#define TCS_LOAD_CHUNK(in_reg, w_reg, C0)                                                                   \
     {                                                                                                       \
+        /* weights first: their address registers alias last chunk's weight registers, and hipcc guards that  \
+           reuse with counted vmcnt waits; issued first, those waits find nothing outstanding */              \
+        const u32x4* wchunk = wsrc + (size_t)((C0) / 16) * w_chunk_units + w_ct;      /* scalar */          \
+        _Pragma("unroll") for (int j = 0; j < W_PT; ++j)                                                    \
+            w_reg[j] = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(                   \
+                (gbytes_t)(const char*)wchunk + (unsigned)w_off[j] * 16u);                                \
         _Pragma("unroll") for (int gi = 0; gi < GPT; ++gi) {                                                \
             const int g0 = (C0) + (part * GPT + gi) * 8;                  /* wave-uniform */                \
             if (a.src_align8) {                                                                             \
                 /* one scalar base pointer per group; loads are unconditional on clamped (valid) addresses and \
                    zero-selected in TCS_STORE_CHUNK, so nothing waits for them before the MFMA phase */      \
-                const float* bj = conv_src_ptr(a, b, min(g0, a.Cin - 8), HWi);    /* scalar; +HWi per channel */ \
+                gptr_t bj = nbase[gi];                                    /* scalar; +HWi per channel */    \
                 _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                             \
                     _Pragma("unroll") for (int k = 0; k < PPT; ++k)                                         \
                         in_reg[(k * GPT + gi) * 8 + j] = bj[max(s_pix[k], 0)];                              \
@@ -124,16 +144,14 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(ConvArgs a) {
                 }                                                                                           \
             } else {                                                                                        \
                 _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                             \
-                    const float* base = conv_src_ptr(a, b, min(g0 + j, a.Cin - 1), HWi);                    \
+                    gptr_t base = conv_src_ptr(a, b, min(g0 + j, a.Cin - 1), HWi);                          \
                     _Pragma("unroll") for (int k = 0; k < PPT; ++k)                                         \
                         in_reg[(k * GPT + gi) * 8 + j] = base[max(s_pix[k], 0)];                            \
                 }                                                                                           \
             }                                                                                               \
         }                                                                                                   \
-        const u32x4* wchunk = wsrc + (size_t)((C0) / 16) * w_chunk_units + w_ct;      /* scalar */          \
-        _Pragma("unroll") for (int j = 0; j < W_PT; ++j) w_reg[j] = wchunk[w_off[j]];                       \
     }
-#define TCS_STORE_CHUNK(C0)                                                                                 \
+#define TCS_STORE_CHUNK(in_reg, w_reg, C0)                                                                                 \
     {                                                                                                       \
         _Pragma("unroll") for (int k = 0; k < PPT; ++k) {                                                   \
             if (s_pix[k] > -2) {                                                                            \
@@ -185,33 +203,96 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(ConvArgs a) {
             acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_hi[m], F.b_hi[p], acc[m][p], 0, 0, 0);   \
         }
 
-    const int cin_loop = (a.Cin + KC - 1) / KC * KC;
-    TCS_LOAD_CHUNK(0)
-    TCS_STORE_CHUNK(0)
+    // compute on the chunk that is in LDS; software pipeline over the KSTEPS*TAPS steps: the ds_reads of step i+1 are
+    // in flight during the MFMAs of step i
+#define TCS_COMPUTE()                                                                                       \
+    {                                                                                                       \
+        constexpr int NSTEP = KSTEPS * TAPS;                                                                \
+        Frag f0, f1;                                                                                        \
+        TCS_FETCH(f0, 0, 0)                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < NSTEP; i += 2) {                                              \
+            if (i + 1 < NSTEP) TCS_FETCH(f1, (i + 1) / TAPS, (i + 1) % TAPS)                                \
+            TCS_MMA(f0)                                                                                     \
+            if (i + 1 < NSTEP) {                                                                            \
+                if (i + 2 < NSTEP) TCS_FETCH(f0, (i + 2) / TAPS, (i + 2) % TAPS)                            \
+                TCS_MMA(f1)                                                                                 \
+            }                                                                                               \
+        }                                                                                                   \
+    }
+
+    const int nchunks = (a.Cin + KC - 1) / KC;
+    TCS_GROUP_BASES(0)
+    TCS_LOAD_CHUNK(in_regA, w_regA, 0)
+    TCS_GROUP_BASES(KC)
+    TCS_STORE_CHUNK(in_regA, w_regA, 0)
     __syncthreads();
-    for (int c0 = 0; c0 < cin_loop; c0 += KC) {
-        const bool has_next = c0 + KC < cin_loop;
-        if (has_next) TCS_LOAD_CHUNK(c0 + KC)
-        // software pipeline over the KSTEPS*TAPS steps: the ds_reads of step i+1 are in flight during the MFMAs of step i
-        constexpr int NSTEP = KSTEPS * TAPS;
-        Frag f0, f1;
-        TCS_FETCH(f0, 0, 0)
-#pragma unroll
-        for (int i = 0; i < NSTEP; i += 2) {
-            if (i + 1 < NSTEP) TCS_FETCH(f1, (i + 1) / TAPS, (i + 1) % TAPS)
-            TCS_MMA(f0)
-            if (i + 1 < NSTEP) {
-                if (i + 2 < NSTEP) TCS_FETCH(f0, (i + 2) / TAPS, (i + 2) % TAPS)
-                TCS_MMA(f1)
+    if (PF == 1) {
+        // global loads of chunk i+1 are in flight during the MFMAs of chunk i
+#ifdef TCS_CONV_STAMPS
+        unsigned long long ts0, ts1, ts2, ts3, ts4, ts5, acc_t[5] = {0, 0, 0, 0, 0};
+#endif
+        for (int i = 0; i < nchunks; ++i) {
+            const bool has_next = i + 1 < nchunks;
+#ifdef TCS_CONV_STAMPS
+            TCS_STAMP(ts0)
+#endif
+            if (has_next) {
+                TCS_LOAD_CHUNK(in_regA, w_regA, (i + 1) * KC)
+                TCS_GROUP_BASES((i + 2) * KC)
+            }
+#ifdef TCS_CONV_STAMPS
+            TCS_STAMP(ts1)
+#endif
+            TCS_COMPUTE()
+#ifdef TCS_CONV_STAMPS
+            TCS_STAMP(ts2)
+#endif
+            if (has_next) {
+                __syncthreads();
+#ifdef TCS_CONV_STAMPS
+                TCS_STAMP(ts3)
+#endif
+                TCS_STORE_CHUNK(in_regA, w_regA, (i + 1) * KC)
+#ifdef TCS_CONV_STAMPS
+                TCS_STAMP(ts4)
+#endif
+                __syncthreads();
+#ifdef TCS_CONV_STAMPS
+                TCS_STAMP(ts5)
+                acc_t[0] += ts1 - ts0; acc_t[1] += ts2 - ts1; acc_t[2] += ts3 - ts2; acc_t[3] += ts4 - ts3; acc_t[4] += ts5 - ts4;
+#endif
             }
         }
-        if (has_next) {
+#ifdef TCS_CONV_STAMPS
+        if (lane == 0) {
+            const size_t w_ = ((size_t)blockIdx.x * 4 + wave) % 16384;
+            for (int q = 0; q < 5; ++q) tcs_conv_stamps[w_ * 8 + q] = acc_t[q];
+            tcs_conv_stamps[w_ * 8 + 5] = nchunks;
+        }
+#endif
+    } else {
+        // two chunks in flight (register sets A and B): a load has two compute phases to land before it is needed.
+        // Used for the narrow tiles, whose MFMA phase is shorter than the memory latency.
+        if (nchunks > 1) TCS_LOAD_CHUNK(in_regA, w_regA, KC)
+        for (int i = 0; i < nchunks; i += 2) {
+            if (i + 2 < nchunks) { TCS_GROUP_BASES((i + 2) * KC) TCS_LOAD_CHUNK(in_regB, w_regB, (i + 2) * KC) }
+            TCS_COMPUTE()                                   // chunk i
+            if (i + 1 >= nchunks) break;
             __syncthreads();
-            TCS_STORE_CHUNK(c0 + KC)
+            TCS_STORE_CHUNK(in_regA, w_regA, (i + 1) * KC)
             __syncthreads();
+            if (i + 3 < nchunks) { TCS_GROUP_BASES((i + 3) * KC) TCS_LOAD_CHUNK(in_regA, w_regA, (i + 3) * KC) }
+            TCS_COMPUTE()                                   // chunk i+1
+            if (i + 2 < nchunks) {
+                __syncthreads();
+                TCS_STORE_CHUNK(in_regB, w_regB, (i + 2) * KC)
+                __syncthreads();
+            }
         }
     }
+#undef TCS_COMPUTE
 #undef TCS_LOAD_CHUNK
+#undef TCS_GROUP_BASES
 #undef TCS_STORE_CHUNK
 #undef TCS_FETCH
 #undef TCS_MMA
@@ -254,11 +335,11 @@ __global__ __launch_bounds__(256) void k_pack_weight_f16x3(const float* __restri
     packed[u] = *reinterpret_cast<uint4*>(&v);
 }
 
-template <int KS, int MT, int MP, int KSTEPS, int EPI, int STRIDE = 1>
+template <int KS, int MT, int MP, int KSTEPS, int EPI, int STRIDE = 1, int PF = 1>
 static int launch_f16(ConvArgs& a, hipStream_t s) {
     constexpr int IH = STRIDE * 4 * MP + KS - STRIDE, IW = STRIDE * 32 + KS - STRIDE, TAPS = KS * KS;
     const size_t lds = (size_t)2 * (2 * KSTEPS) * IH * IW * 16 + (size_t)KSTEPS * TAPS * MT * 2 * 1024;
-    auto kern = k_conv_f16x3<KS, MT, MP, KSTEPS, EPI, STRIDE>;
+    auto kern = k_conv_f16x3<KS, MT, MP, KSTEPS, EPI, STRIDE, PF>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return TCS_ELAUNCH;
@@ -295,7 +376,9 @@ static int launch_f16_tile(ConvArgs& a, hipStream_t s) {
         return mp == 2 ? launch_f16<3, 1, 2, 2, EPI>(a, s) : launch_f16<3, 1, 1, 2, EPI>(a, s);
     }
     if (mt == 2) return mp == 2 ? launch_f16<3, 2, 2, 1, EPI>(a, s) : launch_f16<3, 2, 1, 1, EPI>(a, s);
-    return mp == 2 ? launch_f16<3, 1, 2, 1, EPI>(a, s) : launch_f16<3, 1, 1, 1, EPI>(a, s);
+    if (mp == 2) return launch_f16<3, 1, 2, 1, EPI>(a, s);
+    static const int pf = env_int("TCS_F16_PF");                 // 2 = two chunks in flight (measured slower on MI355X: kept as a knob)
+    return pf == 2 ? launch_f16<3, 1, 1, 1, EPI, 1, 2>(a, s) : launch_f16<3, 1, 1, 1, EPI>(a, s);
 }
 
 template <int EPI>
@@ -346,30 +429,114 @@ __global__ __launch_bounds__(256) void k_deconv_to_conv(const float* __restrict_
     w3[i] = (ky >= 0 && kx >= 0) ? wt[(((size_t)ci * Cout + co) * 4 + ky) * 4 + kx] : 0.f;
 }
 
-// InstanceNorm2d (affine=False): one block per (b, c) plane; two passes over the plane (it lives in L2).
-__global__ __launch_bounds__(256) void k_instance_norm(const float* __restrict__ x, int HW, float eps, int act,
-                                                       const float* __restrict__ addend, float* __restrict__ out) {
-    __shared__ float red[8];
-    const float* p = x + (size_t)blockIdx.x * HW;
-    float s = 0.f;
-    for (int i = threadIdx.x; i < HW; i += 256) s += p[i];
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)HW;
-    float v = 0.f;
-    for (int i = threadIdx.x; i < HW; i += 256) { const float d = p[i] - mean; v = fmaf(d, d, v); }
+// InstanceNorm2d (affine=False): one 1024-thread block per (b, c) plane.  The plane is read ONCE into registers
+// (up to 32 values per thread = 32 768 pixels; larger planes fall back to re-reading), mean and variance are
+// two block reductions (variance around the mean, like the reference's two-pass formula), then the
+// normalised, activated (+ addend) values are written.
+#define IN_T 1024
+#define IN_VPT 32
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {
     v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = v;
     __syncthreads();
-    const float rstd = 1.0f / sqrtf(((red[4] + red[5]) + (red[6] + red[7])) / (float)HW + eps);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < IN_T / 64; ++i) s += red[i];
+    return s;
+}
+
+__global__ __launch_bounds__(IN_T) void k_instance_norm(const float* __restrict__ x, int HW, float eps, int act,
+                                                         const float* __restrict__ addend, float* __restrict__ out) {
+    __shared__ float red[IN_T / 64];
+    const float* p = x + (size_t)blockIdx.x * HW;
     const float* ad = addend ? addend + (size_t)blockIdx.x * HW : nullptr;
     float* o = out + (size_t)blockIdx.x * HW;
-    for (int i = threadIdx.x; i < HW; i += 256) {
-        const float y = apply_act((p[i] - mean) * rstd, act);
-        o[i] = ad ? y + ad[i] : y;
+    const bool cached = HW <= IN_T * IN_VPT;
+    float v[IN_VPT];
+    float s = 0.f;
+    if (cached) {
+#pragma unroll
+        for (int k = 0; k < IN_VPT; ++k) {
+            const int i = threadIdx.x + IN_T * k;
+            v[k] = i < HW ? p[i] : 0.f;
+            s += v[k];
+        }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += IN_T) s += p[i];
+    }
+    const float mean = block_sum_1024(s, red) / (float)HW;
+    float q = 0.f;
+    if (cached) {
+#pragma unroll
+        for (int k = 0; k < IN_VPT; ++k) {
+            const int i = threadIdx.x + IN_T * k;
+            const float d = i < HW ? v[k] - mean : 0.f;
+            q = fmaf(d, d, q);
+        }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += IN_T) { const float d = p[i] - mean; q = fmaf(d, d, q); }
+    }
+    const float rstd = 1.0f / sqrtf(block_sum_1024(q, red) / (float)HW + eps);
+    if (cached) {
+#pragma unroll
+        for (int k = 0; k < IN_VPT; ++k) {
+            const int i = threadIdx.x + IN_T * k;
+            if (i < HW) {
+                const float y = apply_act((v[k] - mean) * rstd, act);
+                o[i] = ad ? y + ad[i] : y;
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += IN_T) {
+            const float y = apply_act((p[i] - mean) * rstd, act);
+            o[i] = ad ? y + ad[i] : y;
+        }
     }
 }
+
+// 3x3 convolution with ONE output channel (FlowHead.conv2 256->1, update.py:13): a matrix-core tile would waste 31
+// of 32 output columns, so this is a plain reduction: a wave owns 64 consecutive pixels, lanes = pixels, the 4 waves
+// of a block split the input channels and combine through LDS.  Weights are wave-uniform scalar loads.
+__global__ __launch_bounds__(256) void k_conv3x3_cout1(const float* __restrict__ x, const float* __restrict__ w /*[Cin][9]*/,
+                                                       const float* __restrict__ bias, int Cin, int H, int W,
+                                                       float* __restrict__ out) {
+    __shared__ float part[4][64];
+    const int b = blockIdx.y, HW = H * W;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = blockIdx.x * 64 + lane;
+    const int pc = min(p, HW - 1);
+    const int y = pc / W, xx = pc - y * W;
+    int off[9];
+    bool ok[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xc = xx + t % 3 - 1;
+        ok[t] = yy >= 0 && yy < H && xc >= 0 && xc < W;
+        off[t] = ok[t] ? yy * W + xc : pc;
+    }
+    const int cpw = (Cin + 3) / 4;
+    const int c_lo = wave * cpw, c_hi = min(Cin, c_lo + cpw);
+    float acc = 0.f;
+    for (int c = c_lo; c < c_hi; ++c) {
+        const float* xp = x + ((size_t)b * Cin + c) * HW;
+        const float* wp = w + (size_t)c * 9;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float v = xp[off[t]];
+            acc = fmaf(wp[t], ok[t] ? v : 0.f, acc);
+        }
+    }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && p < HW) out[(size_t)b * HW + p] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]) + (bias ? bias[0] : 0.f);
+}
+
+#ifdef TCS_CONV_STAMPS
+extern "C" int tcs_debug_read_conv_stamps(unsigned long long* host_out, int n_waves) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(tcs_conv_stamps), (size_t)n_waves * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" {
 
@@ -387,8 +554,16 @@ int tcs_pack_deconv4x4s2_f16x3(const float* w_iohw, int Cin, int Cout, int scale
 int tcs_instance_norm(const float* x, int B, int C, int H, int W, float eps, int act, const float* addend, float* out,
                       tcs_stream_t stream) {
     if (!x || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0 || eps < 0.f) return TCS_EINVAL;
-    hipLaunchKernelGGL(k_instance_norm, dim3((unsigned)((size_t)B * C)), dim3(256), 0, tcs_stream(stream), x, H * W, eps, act,
+    hipLaunchKernelGGL(k_instance_norm, dim3((unsigned)((size_t)B * C)), dim3(IN_T), 0, tcs_stream(stream), x, H * W, eps, act,
                        addend, out);
+    return tcs_launch_status();
+}
+
+int tcs_conv3x3_cout1(const float* x, const float* w_oihw, const float* bias, int B, int Cin, int H, int W, float* out,
+                      tcs_stream_t stream) {
+    if (!x || !w_oihw || !out || B <= 0 || B > 65535 || Cin <= 0 || H <= 0 || W <= 0) return TCS_EINVAL;
+    hipLaunchKernelGGL(k_conv3x3_cout1, dim3(tcs_cdiv((long long)H * W, 64), B), dim3(256), 0, tcs_stream(stream), x, w_oihw, bias,
+                       Cin, H, W, out);
     return tcs_launch_status();
 }
 

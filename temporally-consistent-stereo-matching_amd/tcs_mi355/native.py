@@ -73,6 +73,7 @@ SIGNATURES = {
     "tcs_deconv_packed_floats_f16x3": (c_sz, [c_int, c_int]),
     "tcs_pack_deconv4x4s2_f16x3": (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp]),
     "tcs_instance_norm": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_f, c_int, c_fp, c_fp, c_fp]),
+    "tcs_conv3x3_cout1": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp]),
     "tcs_conv2d": (c_int, [C.POINTER(ConvDesc), c_fp]),
 }
 

@@ -416,6 +416,19 @@ def conv2d(pc: PackedConv, srcs: Sequence[torch.Tensor], act: str = "none", adde
     return out
 
 
+def conv3x3_cout1(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """Conv2d(Cin, 1, 3, padding=1) on the un-packed weight (tcs_conv3x3_cout1)."""
+    B, Cin, H, W = _dims4(x, "x")
+    if tuple(weight.shape) != (1, Cin, 3, 3):
+        raise ValueError(f"expected a [1,{Cin},3,3] weight, got {tuple(weight.shape)}")
+    out = _new(x, B, 1, H, W)
+    w = weight.detach().float().contiguous()
+    b = None if bias is None else bias.detach().float().contiguous()
+    nv.check(nv.lib().tcs_conv3x3_cout1(nv.ptr(x, "x"), nv.ptr(w, "weight"), nv.ptr(b, "bias"), B, Cin, H, W, nv.ptr(out), nv.stream()),
+             "tcs_conv3x3_cout1")
+    return out
+
+
 def gru_gates(pc_zr: PackedConv, srcs, h, cz=None, cr=None, z_out=None, rh_out=None):
     """z = sigmoid(conv_zr[:hid] + cz), rh = sigmoid(conv_zr[hid:] + cr) * h   (update.py:81-83, 30-33)."""
     d = _desc(pc_zr, srcs)
