@@ -33,6 +33,15 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 LOOKUP_BYTES_PER_PIXEL = 308    # 4 levels x 10 taps x 4 B + 4 B coord + 36 x 4 B out
 
 
+def _contraction():
+    m = os.environ.get("TCS_MI355_MATH", "f16x3")
+    return ("fp16 hi/lo split operands, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate (error <= fp32 MFMA chain; "
+            "tests/test_gpu_parity.py::test_f16x3_split_is_fp32_grade)") if m == "f16x3" else "fp32 MFMA (v_mfma_f32_32x32x2_f32)"
+
+
+CONTRACTION = _contraction()
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -97,10 +106,24 @@ def lookup_roofline(probe, snapshots):
     dur_us = float(np.mean(durs))
     alg_bytes = LOOKUP_BYTES_PER_PIXEL * probe.pixels
     achieved = alg_bytes / (dur_us * 1e-6) / 1e9
-    return {"bound": "hbm", "kernel": "k_corr_lookup<4>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roof = {"bound": "hbm", "kernel": "k_corr_lookup<4>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_us": round(dur_us, 3),
             "min_launch_us": round(float(np.min(durs)), 3), "launches": len(durs), "algorithmic_bytes_per_launch": alg_bytes,
             "timer": "in-kernel s_memrealtime stamps (100 MHz), every lookup launch of the timed region"}
+    # PMC traffic and rocprofv3's own duration come from the committed profile of this same command (profiles/README.md):
+    # bench.py cannot run the profiler on itself.  rocprofv3's per-dispatch interval carries ~2.3 us of dispatch/completion
+    # overhead on this stack (trivial kernels read 4.4-4.7 us), so it is quoted next to the in-kernel interval, not instead.
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_lookup_pmc.json")) as f:
+            pmc = json.load(f)
+        if pmc.get("algorithmic_bytes_per_launch") == alg_bytes:
+            roof["traffic"] = pmc["traffic_bytes_per_launch"]
+            roof["traffic_source"] = "profiles/r01_lookup_pmc.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc passes)"
+            roof["rocprof_avg_launch_us"] = pmc["rocprof_kernel_trace_avg_us"]
+            roof["frac_at_rocprof_duration"] = round(alg_bytes / (pmc["rocprof_kernel_trace_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+    except (OSError, KeyError, ValueError):
+        pass
+    return roof
 
 
 def cpu_baseline(W, seq, gpu_preds, n_frames=2):
@@ -202,6 +225,7 @@ def main():
             "metric": "stereo-pairs/sec at 640x480 D=192, 32 GRU iters", "value": round(value, 4), "unit": "stereo-pairs/s",
             "n_gpus": max(world, 1), "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "contraction": CONTRACTION,
             "config": {"workload": "BASELINE configs[1]: 640x480 synthetic sequence len=10, D=192, 32 iters, one sequence per GPU",
                        "frames_per_rank": a.steps, "weights": "key-seeded synthetic (tcs_mi355.weights)",
                        "launch": "eager" if a.eager else "hip-graph replay"},

@@ -17,6 +17,7 @@ import torch.nn.functional as F
 
 from core.utils.basic_layers import Conv2x_IN
 from tcs_mi355 import ops
+from tcs_mi355.streams import fork_join
 
 
 # ---------------------------------------------------------------------------------------------
@@ -186,8 +187,9 @@ class BasicMotionEncoder(nn.Module):
 
     def forward(self, flow, corr):
         flow = flow.float().contiguous()
-        cor = hip_conv(self.convc2, [hip_conv(self.convc1, [corr], act="relu")], act="relu")
-        flo = hip_conv(self.convf2, [hip_conv(self.convf1, [flow], act="relu")], act="relu")
+        cor, flo = fork_join([
+            lambda: hip_conv(self.convc2, [hip_conv(self.convc1, [corr], act="relu")], act="relu"),
+            lambda: hip_conv(self.convf2, [hip_conv(self.convf1, [flow], act="relu")], act="relu")])
         n, _, h, w = flow.shape
         out = torch.empty(n, 128, h, w, dtype=torch.float32, device=flow.device)
         hip_conv(self.conv, [cor, flo], act="relu", out=out)     # channels 0..126 in place: no torch.cat
@@ -226,15 +228,21 @@ class BasicMultiUpdateBlock(nn.Module):
     def forward(self, net, inp, corr=None, flow=None, iter08=True, iter16=True, iter32=True, update=True):
         """Coarse-to-fine GRU sweep (update.py:145-168); `net` is updated in place like the reference."""
         n = self.args.n_gru_layers
-        if iter32:
-            net[2] = self.gru32(net[2], *inp[2], pool2x(net[1]))
-        if iter16:
-            extra = (interp(net[2], net[1]),) if n > 2 else ()
-            net[1] = self.gru16(net[1], *inp[1], pool2x(net[0]), *extra)
+
+        def coarse():            # gru32 -> gru16: independent of the motion encoder (which only feeds gru08)
+            if iter32:
+                net[2] = self.gru32(net[2], *inp[2], pool2x(net[1]))
+            if iter16:
+                extra = (interp(net[2], net[1]),) if n > 2 else ()
+                net[1] = self.gru16(net[1], *inp[1], pool2x(net[0]), *extra)
+            return interp(net[1], net[0]) if (iter08 and n > 1) else None
+
         if iter08:
-            motion = self.encoder(flow, corr)
-            extra = (interp(net[1], net[0]),) if n > 1 else ()
+            up16, motion = fork_join([coarse, lambda: self.encoder(flow, corr)])
+            extra = (up16,) if n > 1 else ()
             net[0] = self.gru08(net[0], *inp[0], motion, *extra)
+        else:
+            coarse()
         if not update:
             return net
         return net, self.flow_head(net[0])
@@ -276,8 +284,8 @@ class DispGradPredictor(nn.Module):
         disp = disp.float().contiguous()
         g5 = (5 * disp_grad).contiguous()                        # update.py:199
         cands = ops.grad_candidates(disp)                        # [N,32,H,W] (update.py:202-204)
-        x4_grad = hip_seq(self.conv_grad_stem, [g5])
-        x4_cand = hip_seq(self.conv_grad_candidate_stem, [cands])
+        x4_grad, x4_cand = fork_join([lambda: hip_seq(self.conv_grad_stem, [g5]),
+                                      lambda: hip_seq(self.conv_grad_candidate_stem, [cands])])
         x4 = hip_seq(self.conv_4_4, [x4_grad, x4_cand, clist[0]])
         s2 = hip_ok_stride2()
         x8 = hip_seq(self.conv_4_8, [x4]) if s2 else self.conv_4_8(x4)          # 3x3 stride 2
@@ -286,8 +294,8 @@ class DispGradPredictor(nn.Module):
         x16 = hip_seq(self.conv_16_16, [x16, clist[2]])
         x8_up = self._up(self.conv_16_8, x16, x8)
         x4_up = self._up(self.conv_8_4, x8_up, x4)
-        res = hip_seq(self.residual_head, [x4_up])
-        return (g5 + res) / 5, hip_seq(self.conv_out, [x4_up])
+        grad, ctx = fork_join([lambda: (g5 + hip_seq(self.residual_head, [x4_up])) / 5, lambda: hip_seq(self.conv_out, [x4_up])])
+        return grad, ctx
 
 
 class DispRefine(nn.Module):
@@ -311,9 +319,11 @@ class DispRefine(nn.Module):
 
     def forward(self, disp_grads, disp, context_disp, context_grad, test_mode=False):
         disp = disp.float().contiguous()
-        context = hip_seq(self.context_compress, [context_disp, context_grad])
-        feats27 = self._prop(disp_grads, disp)                    # cat(candidates, matrix) laid out by the kernel
-        disp_f = hip_seq(self.disp_f_stem, [feats27])
+        def cand_branch():
+            f27 = self._prop(disp_grads, disp)                    # cat(candidates, matrix) laid out by the kernel
+            return f27, hip_seq(self.disp_f_stem, [f27])
+
+        context, (feats27, disp_f) = fork_join([lambda: hip_seq(self.context_compress, [context_disp, context_grad]), cand_branch])
         fused = hip_seq(self.conv_fuse, [disp_f, context])
         logits = hip_seq(self.w_head, [fused])
         refined, _ = ops.softmax_blend(logits, feats27)

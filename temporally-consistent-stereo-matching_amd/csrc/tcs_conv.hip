@@ -19,6 +19,8 @@
 // (round-robin dispatch), so with 1, 2, 4 or 8 cout tiles every XCD's L2 holds a single weight slice.
 #include "tcs_conv_common.h"
 
+extern "C" size_t tcs_conv_packed_floats_f16x3(int Cout, int Cin, int ksize);
+
 template <int KS, int MT, int KC, int EPI>
 __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a) {
     constexpr int NT = 32 * MT, HALO = KS / 2, IH = 4 + KS - 1, IW = 32 + KS - 1, TAPS = KS * KS;
@@ -239,6 +241,7 @@ int tcs_conv2d(const tcs_conv_desc* d, tcs_stream_t stream) {
     a.npatch = a.npx * tcs_cdiv(d->H, 4);
     a.nct = a.CoutPad / nt;
     a.w_unscale = 1.0f;
+    a.w_bytes = 0;
     hipStream_t s = tcs_stream(stream);
 
     if (d->math == TCS_MATH_F16X3) {
@@ -254,6 +257,7 @@ int tcs_conv2d(const tcs_conv_desc* d, tcs_stream_t stream) {
         if (d->epilogue == TCS_EPI_DECONV2X) a.hidden = d->Cout / 4;
         a.CoutPad = round_up(d->Cout, 32);
         a.w_unscale = d->weight_unscale;
+        a.w_bytes = (int)(tcs_conv_packed_floats_f16x3(d->Cout, d->Cin, d->ksize) * sizeof(float));
         a.npx = tcs_cdiv(a.W, 32);
         return tcs_conv_f16x3_launch(a, d->ksize, d->epilogue, stride, s);
     }

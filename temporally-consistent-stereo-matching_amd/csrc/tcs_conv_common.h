@@ -25,6 +25,7 @@ struct ConvArgs {
     float* out2;
     int npx, npatch, nct;
     int src_align8;         // every source boundary is a multiple of 8 channels (one source select per 8-channel group)
+    int w_bytes;            // size of the packed weight buffer (buffer-load bound)
     float w_unscale;        // fp16-split kernel: 2^-s undoing the weight pre-scale (1 for the fp32 kernel)
 };
 

@@ -1,0 +1,53 @@
+"""Fork/join of independent launch chains onto side HIP streams.
+
+Inside one refinement iteration several chains of small kernels do not depend on each other (the two halves of the
+motion encoder and the coarse GRUs; the two stems of the gradient predictor; its two heads; the context branch and the
+candidate branch of DispRefine).  Each of those kernels fills only part of the 256 CUs, so running the chains
+side by side raises occupancy.  Under HIP-graph capture the fork/join becomes parallel branches of the graph.
+
+OFF by default: on ROCm 7.2 `hipStreamEndCapture` segfaults on the forked capture of a whole frame (≈1,800 nodes),
+so the default (graph replay) path stays single-stream.  Enable with TCS_MI355_STREAMS=1 together with eager
+launches (TCS_MI355_GRAPH=0) to experiment.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, List, Sequence
+
+import torch
+
+ENABLED = os.environ.get("TCS_MI355_STREAMS", "0") == "1"
+_POOL: dict = {}
+_DEPTH = 0          # nesting level of fork_join: each level owns its own side streams (a nested fork must never
+                    # pick the stream it is already running on)
+
+
+def _side_streams(device, depth: int, n: int) -> List[torch.cuda.Stream]:
+    pool = _POOL.setdefault((device, depth), [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
+def fork_join(fns: Sequence[Callable[[], object]]) -> list:
+    """Run fns[0] on the current stream and fns[1:] on side streams; returns their results after joining.
+    Every side chain starts after everything already enqueued on the current stream and the current stream waits for
+    every side chain before continuing, so memory handed between the chains is ordered."""
+    if not ENABLED or len(fns) <= 1 or not torch.cuda.is_available():
+        return [f() for f in fns]
+    global _DEPTH
+    cur = torch.cuda.current_stream()
+    sides = _side_streams(cur.device, _DEPTH, len(fns) - 1)
+    results = [None] * len(fns)
+    _DEPTH += 1
+    try:
+        for i, st in enumerate(sides, start=1):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                results[i] = fns[i]()
+        results[0] = fns[0]()
+    finally:
+        _DEPTH -= 1
+    for st in sides:
+        cur.wait_stream(st)
+    return results
