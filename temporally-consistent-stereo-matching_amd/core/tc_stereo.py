@@ -177,13 +177,13 @@ class TCStereo(nn.Module):
                 net_list = self.update_block(net_list, inp_list, iter32=n3, iter16=True, iter08=False, update=False)
             net_list, delta_flow = self.update_block(net_list, inp_list, corr, flows_x, iter32=n3, iter16=a.n_gru_layers >= 2)
             disp_q = ops.flow_step(coords1, delta_flow)                        # coords1 += delta; disp_q = x - coords1
-            disp_grad = ops.disp_gradient_xy(disp_q)
-            disp_grad, context = self.disp_grad_refine(disp_grad, disp_q, grad_list)
+            g5 = ops.disp_gradient_xy(disp_q, scale=5.0)                       # 5 * disp2disp_gradient_xy (update.py:199)
+            disp_grad, context = self.disp_grad_refine(None, disp_q, grad_list, g5=g5)
             last = itr == iters - 1
-            refined, up_mask = self.disp_refine(disp_grad, disp_q, net_list[0], context, test_mode=not last)
-            delta_disp = refined - disp_q
-            net_list = [self.hiddenstate_update(net_list[0], delta_disp), net_list[1], net_list[2]]
-            coords1 = (coords0 - refined).contiguous()
+            fused = {}
+            refined, up_mask = self.disp_refine(disp_grad, disp_q, net_list[0], context, test_mode=not last, fused_outputs=fused)
+            net_list = [self.hiddenstate_update(net_list[0], fused["delta_disp"]), net_list[1], net_list[2]]
+            coords1 = fused["coords1"]
             if trace is not None:
                 trace["iters"].append(dict(corr=corr, delta=delta_flow, disp_q=disp_q, refined=refined,
                                            net=[t.clone() for t in net_list]))

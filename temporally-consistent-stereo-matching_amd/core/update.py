@@ -280,9 +280,11 @@ class DispGradPredictor(nn.Module):
             y = F.interpolate(y, size=rem.shape[-2:], mode="nearest")
         return hip_conv(block.conv2.conv, [(y + rem)], act="leaky")
 
-    def forward(self, disp_grad, disp, clist):
+    def forward(self, disp_grad, disp, clist, g5=None):
+        """`g5`, when given, is 5*disp_grad already produced by the gradient kernel (saves an elementwise launch)."""
         disp = disp.float().contiguous()
-        g5 = (5 * disp_grad).contiguous()                        # update.py:199
+        if g5 is None:
+            g5 = (5 * disp_grad).contiguous()                    # update.py:199
         cands = ops.grad_candidates(disp)                        # [N,32,H,W] (update.py:202-204)
         x4_grad, x4_cand = fork_join([lambda: hip_seq(self.conv_grad_stem, [g5]),
                                       lambda: hip_seq(self.conv_grad_candidate_stem, [cands])])
@@ -294,7 +296,12 @@ class DispGradPredictor(nn.Module):
         x16 = hip_seq(self.conv_16_16, [x16, clist[2]])
         x8_up = self._up(self.conv_16_8, x16, x8)
         x4_up = self._up(self.conv_8_4, x8_up, x4)
-        grad, ctx = fork_join([lambda: (g5 + hip_seq(self.residual_head, [x4_up])) / 5, lambda: hip_seq(self.conv_out, [x4_up])])
+        def head():
+            # (5*grad + residual) / 5 (update.py:213) in the epilogue of the last conv: addend = 5*grad, scale = 1/5
+            h = hip_conv(self.residual_head[0], [x4_up], act="relu")
+            return hip_conv(self.residual_head[2], [h], addend=g5, post_scale=0.2)
+
+        grad, ctx = fork_join([head, lambda: hip_seq(self.conv_out, [x4_up])])
         return grad, ctx
 
 
@@ -317,7 +324,9 @@ class DispRefine(nn.Module):
         buf = self._prop(disparity_grad, disparity_map)
         return buf[:, :9], buf[:, 9:]
 
-    def forward(self, disp_grads, disp, context_disp, context_grad, test_mode=False):
+    def forward(self, disp_grads, disp, context_disp, context_grad, test_mode=False, fused_outputs=None):
+        """`fused_outputs`, when a dict, receives 'delta_disp' (= refined - disp) and 'coords1' (= x - refined) straight
+        from the blend kernel (tc_stereo.py:198-202), saving two elementwise launches."""
         disp = disp.float().contiguous()
         def cand_branch():
             f27 = self._prop(disp_grads, disp)                    # cat(candidates, matrix) laid out by the kernel
@@ -326,7 +335,12 @@ class DispRefine(nn.Module):
         context, (feats27, disp_f) = fork_join([lambda: hip_seq(self.context_compress, [context_disp, context_grad]), cand_branch])
         fused = hip_seq(self.conv_fuse, [disp_f, context])
         logits = hip_seq(self.w_head, [fused])
-        refined, _ = ops.softmax_blend(logits, feats27)
+        if fused_outputs is not None:
+            coords1 = torch.empty_like(disp)
+            refined, delta = ops.softmax_blend(logits, feats27, disp_q=disp, want_delta=True, coords1=coords1)
+            fused_outputs.update(delta_disp=delta, coords1=coords1)
+        else:
+            refined, _ = ops.softmax_blend(logits, feats27)
         mask = None
         if not test_mode:
             mask = hip_conv(self.mask[2], [hip_conv(self.mask[0], [fused], act="relu")], post_scale=0.25)
