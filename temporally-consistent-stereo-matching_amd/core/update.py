@@ -189,7 +189,7 @@ class BasicMotionEncoder(nn.Module):
         flow = flow.float().contiguous()
         cor, flo = fork_join([
             lambda: hip_conv(self.convc2, [hip_conv(self.convc1, [corr], act="relu")], act="relu"),
-            lambda: hip_conv(self.convf2, [hip_conv(self.convf1, [flow], act="relu")], act="relu")])
+            lambda: hip_conv(self.convf2, [hip_conv(self.convf1, [flow], act="relu")], act="relu")], site="enc")
         n, _, h, w = flow.shape
         out = torch.empty(n, 128, h, w, dtype=torch.float32, device=flow.device)
         hip_conv(self.conv, [cor, flo], act="relu", out=out)     # channels 0..126 in place: no torch.cat
@@ -238,7 +238,9 @@ class BasicMultiUpdateBlock(nn.Module):
             return interp(net[1], net[0]) if (iter08 and n > 1) else None
 
         if iter08:
-            up16, motion = fork_join([coarse, lambda: self.encoder(flow, corr)])
+            # the encoder (which forks again) stays on the current stream: ROCm 7.2 segfaults in hipStreamEndCapture when
+            # a side branch of a captured fork forks a second time
+            motion, up16 = fork_join([lambda: self.encoder(flow, corr), coarse], site="coarse")
             extra = (up16,) if n > 1 else ()
             net[0] = self.gru08(net[0], *inp[0], motion, *extra)
         else:
@@ -287,7 +289,7 @@ class DispGradPredictor(nn.Module):
             g5 = (5 * disp_grad).contiguous()                    # update.py:199
         cands = ops.grad_candidates(disp)                        # [N,32,H,W] (update.py:202-204)
         x4_grad, x4_cand = fork_join([lambda: hip_seq(self.conv_grad_stem, [g5]),
-                                      lambda: hip_seq(self.conv_grad_candidate_stem, [cands])])
+                                      lambda: hip_seq(self.conv_grad_candidate_stem, [cands])], site="stems")
         x4 = hip_seq(self.conv_4_4, [x4_grad, x4_cand, clist[0]])
         s2 = hip_ok_stride2()
         x8 = hip_seq(self.conv_4_8, [x4]) if s2 else self.conv_4_8(x4)          # 3x3 stride 2
@@ -301,7 +303,7 @@ class DispGradPredictor(nn.Module):
             h = hip_conv(self.residual_head[0], [x4_up], act="relu")
             return hip_conv(self.residual_head[2], [h], addend=g5, post_scale=0.2)
 
-        grad, ctx = fork_join([head, lambda: hip_seq(self.conv_out, [x4_up])])
+        grad, ctx = fork_join([head, lambda: hip_seq(self.conv_out, [x4_up])], site="heads")
         return grad, ctx
 
 
@@ -332,7 +334,7 @@ class DispRefine(nn.Module):
             f27 = self._prop(disp_grads, disp)                    # cat(candidates, matrix) laid out by the kernel
             return f27, hip_seq(self.disp_f_stem, [f27])
 
-        context, (feats27, disp_f) = fork_join([lambda: hip_seq(self.context_compress, [context_disp, context_grad]), cand_branch])
+        context, (feats27, disp_f) = fork_join([lambda: hip_seq(self.context_compress, [context_disp, context_grad]), cand_branch], site="refine")
         fused = hip_seq(self.conv_fuse, [disp_f, context])
         logits = hip_seq(self.w_head, [fused])
         if fused_outputs is not None:

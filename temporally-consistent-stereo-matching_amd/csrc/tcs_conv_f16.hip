@@ -203,6 +203,45 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(ConvArgs a) {
             acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_hi[m], F.b_hi[p], acc[m][p], 0, 0, 0);   \
         }
 
+#ifdef TCS_ASM_FETCH
+    // Hand-pipelined operand fetch: inline-asm ds_read_b128 with counted s_waitcnt, so that the R = 2*MP + 2*MT reads of
+    // step i+1 are in flight during the 3*MT*MP MFMAs of step i (hipcc puts compiler-visible ds_reads right in front of
+    // their consumer with lgkmcnt(0)).  This kernel has no static __shared__, so the dynamic segment starts at
+    // __builtin_amdgcn_groupstaticsize().
+    const unsigned lds_base = __builtin_amdgcn_groupstaticsize();
+    const unsigned addr_b = lds_base + (unsigned)((half * IN_CH + wave * MP * STRIDE * IW + STRIDE * l31) * 16);
+    const unsigned addr_a = lds_base + (unsigned)(2 * IN_BYTES + lane * 16);
+    // the immediate offset field is 16 bits; the (compile-time) part above 32 KB goes into the address register
+#define TCS_DSREAD(DST, ADDR, OFF) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"((ADDR) + (unsigned)((OFF) & ~0x7fff)), "i"((OFF) & 0x7fff) : "memory")
+#define TCS_FETCH_ASM(F, KSI, T)                                                                            \
+    {                                                                                                       \
+        _Pragma("unroll") for (int p = 0; p < MP; ++p) {                                                    \
+            TCS_DSREAD(F.b_hi[p], addr_b, ((2 * (KSI)) * IN_CH + (STRIDE * p + (T) / KS) * IW + (T) % KS) * 16);            \
+            TCS_DSREAD(F.b_lo[p], addr_b, ((2 * (KSI)) * IN_CH + (STRIDE * p + (T) / KS) * IW + (T) % KS) * 16 + IN_BYTES); \
+        }                                                                                                   \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                    \
+            TCS_DSREAD(F.a_hi[m], addr_a, (((KSI) * TAPS + (T)) * MT + m) * 2048);                          \
+            TCS_DSREAD(F.a_lo[m], addr_a, (((KSI) * TAPS + (T)) * MT + m) * 2048 + 1024);                   \
+        }                                                                                                   \
+    }
+#define TCS_WAIT_LGKM(N) { asm volatile("s_waitcnt lgkmcnt(%0)" :: "i"(N) : "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define TCS_COMPUTE()                                                                                       \
+    {                                                                                                       \
+        constexpr int NSTEP = KSTEPS * TAPS, R = 2 * MP + 2 * MT;                                           \
+        static_assert(R <= 15, "lgkmcnt field");                                                            \
+        Frag f0, f1;                                                                                        \
+        TCS_FETCH_ASM(f0, 0, 0)                                                                             \
+        _Pragma("unroll") for (int i = 0; i < NSTEP; i += 2) {                                              \
+            if (i + 1 < NSTEP) { TCS_FETCH_ASM(f1, (i + 1) / TAPS, (i + 1) % TAPS) TCS_WAIT_LGKM(R) } else TCS_WAIT_LGKM(0) \
+            TCS_MMA(f0)                                                                                     \
+            if (i + 1 < NSTEP) {                                                                            \
+                if (i + 2 < NSTEP) { TCS_FETCH_ASM(f0, (i + 2) / TAPS, (i + 2) % TAPS) TCS_WAIT_LGKM(R) } else TCS_WAIT_LGKM(0) \
+                TCS_MMA(f1)                                                                                 \
+            }                                                                                               \
+        }                                                                                                   \
+    }
+#else
     // compute on the chunk that is in LDS; software pipeline over the KSTEPS*TAPS steps: the ds_reads of step i+1 are
     // in flight during the MFMAs of step i
 #define TCS_COMPUTE()                                                                                       \
@@ -220,6 +259,7 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(ConvArgs a) {
         }                                                                                                   \
     }
 
+#endif
     const int nchunks = (a.Cin + KC - 1) / KC;
     TCS_GROUP_BASES(0)
     TCS_LOAD_CHUNK(in_regA, w_regA, 0)
@@ -236,14 +276,19 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(ConvArgs a) {
 #ifdef TCS_CONV_STAMPS
             TCS_STAMP(ts0)
 #endif
+            // TCS_ABLATE_* are diagnostic builds (tools/conv_ablate.sh): results are wrong, only the timing is of interest
+#ifndef TCS_ABLATE_LOAD
             if (has_next) {
                 TCS_LOAD_CHUNK(in_regA, w_regA, (i + 1) * KC)
                 TCS_GROUP_BASES((i + 2) * KC)
             }
+#endif
 #ifdef TCS_CONV_STAMPS
             TCS_STAMP(ts1)
 #endif
+#ifndef TCS_ABLATE_MMA
             TCS_COMPUTE()
+#endif
 #ifdef TCS_CONV_STAMPS
             TCS_STAMP(ts2)
 #endif
@@ -252,7 +297,9 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(ConvArgs a) {
 #ifdef TCS_CONV_STAMPS
                 TCS_STAMP(ts3)
 #endif
+#ifndef TCS_ABLATE_STORE
                 TCS_STORE_CHUNK(in_regA, w_regA, (i + 1) * KC)
+#endif
 #ifdef TCS_CONV_STAMPS
                 TCS_STAMP(ts4)
 #endif

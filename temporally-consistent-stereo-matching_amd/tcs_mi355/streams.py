@@ -17,6 +17,7 @@ from typing import Callable, List, Sequence
 import torch
 
 ENABLED = os.environ.get("TCS_MI355_STREAMS", "0") == "1"
+SITES = os.environ.get("TCS_MI355_FORK_SITES", "all").split(",")       # diagnostic: restrict forking to named call sites
 _POOL: dict = {}
 _DEPTH = 0          # nesting level of fork_join: each level owns its own side streams (a nested fork must never
                     # pick the stream it is already running on)
@@ -29,11 +30,11 @@ def _side_streams(device, depth: int, n: int) -> List[torch.cuda.Stream]:
     return pool[:n]
 
 
-def fork_join(fns: Sequence[Callable[[], object]]) -> list:
+def fork_join(fns: Sequence[Callable[[], object]], site: str = "") -> list:
     """Run fns[0] on the current stream and fns[1:] on side streams; returns their results after joining.
     Every side chain starts after everything already enqueued on the current stream and the current stream waits for
     every side chain before continuing, so memory handed between the chains is ordered."""
-    if not ENABLED or len(fns) <= 1 or not torch.cuda.is_available():
+    if not ENABLED or len(fns) <= 1 or not torch.cuda.is_available() or ("all" not in SITES and site not in SITES):
         return [f() for f in fns]
     global _DEPTH
     cur = torch.cuda.current_stream()
