@@ -49,21 +49,28 @@ __device__ __forceinline__ void split_f16x2(float x0, float x1, half2_t& hi, hal
 }
 
 // MT = 32-wide output-channel tiles per wave, MP = patch rows per wave (block patch = 4*MP rows x 32 columns),
-// KSTEPS = 16-channel MFMA K-steps per LDS chunk.
-template <int KS, int MT, int MP, int KSTEPS, int EPI, int STRIDE = 1, int PF = 1>
-__global__ __launch_bounds__(256) void k_conv_f16x3(ConvArgs a) {
+// KSTEPS = 16-channel MFMA K-steps per LDS chunk, WM = wave groups along the output channels: the block has 4*WM waves
+// and covers 32*MT*WM output channels; wave (row, g) owns patch row(s) `row` and tiles g*MT .. g*MT+MT-1.
+// A wave issues one instruction every ~4-5 cycles, and a chunk costs ~700 non-MFMA instructions per block (loads,
+// fp16 split, LDS traffic) against 27*MT*MP MFMAs per wave: with 4 waves the block is issue-bound at 4-5x the MFMA time
+// (measured with in-kernel stamps, tools/conv_phases.py).  WM = 2 halves the staging work per wave and doubles the
+// waves that share one LDS image.
+template <int KS, int MT, int MP, int KSTEPS, int EPI, int STRIDE = 1, int PF = 1, int WM = 1>
+__global__ __launch_bounds__(256 * WM) void k_conv_f16x3(ConvArgs a) {
+    constexpr int NTHREADS = 256 * WM, MTB = MT * WM;                          // MTB: cout tiles per block
     constexpr int HALO = KS / 2, PR = 4 * MP, IH = STRIDE * PR + KS - STRIDE, IW = STRIDE * 32 + KS - STRIDE, TAPS = KS * KS,
                   IN_CH = IH * IW;
-    constexpr int NT = 32 * MT, KC = 16 * KSTEPS, NG = 2 * KSTEPS;            // NG: 8-channel groups per chunk
+    constexpr int NT = 32 * MTB, KC = 16 * KSTEPS, NG = 2 * KSTEPS;           // NG: 8-channel groups per chunk
     constexpr int IN_BYTES = NG * IN_CH * 16;                                  // one of {hi, lo}
-    constexpr int W_UNITS = KSTEPS * TAPS * MT * 2 * 64;                       // 16-byte units per chunk
+    constexpr int W_UNITS = KSTEPS * TAPS * MTB * 2 * 64;                      // 16-byte units per chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
     unsigned char* s_in_hi = lds8;
     unsigned char* s_in_lo = lds8 + IN_BYTES;
     unsigned char* s_w = lds8 + 2 * IN_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_all & 3, wave_g = wave_all >> 2;                    // patch row, cout group
     const int bid = blockIdx.x;
     const int ct = bid % a.nct, patch = bid / a.nct;
     const int b = blockIdx.y;
@@ -84,8 +91,8 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(ConvArgs a) {
     // A thread owns PPT halo positions and, for each, GPT of the chunk's NG 8-channel groups.  The group index
     // is uniform across a wave (across the block when PARTS == 1), so the per-chunk base pointer of a group is
     // computed on the scalar unit and every load is `global_load_dword v, v_pixel_offset, s[base]`.
-    constexpr int PARTS = (IN_CH <= 128) ? 2 : 1;             // 1x1 convs: two half-blocks split the groups
-    constexpr int TPP = 256 / PARTS;                          // threads per part
+    constexpr int PARTS = NTHREADS / ((IN_CH <= 128) ? 128 : 256);   // thread groups that split the channel groups
+    constexpr int TPP = NTHREADS / PARTS;                     // threads per part
     constexpr int PPT = (IN_CH + TPP - 1) / TPP;              // positions per thread
     constexpr int GPT = NG / PARTS;                           // groups per thread
     static_assert(NG % PARTS == 0, "groups must split evenly");
@@ -99,18 +106,18 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(ConvArgs a) {
         const int gy = STRIDE * y0 - HALO + sr, gx = STRIDE * x0 - HALO + sc;
         s_pix[k] = pos >= IN_CH ? -2 : ((gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) ? gy * a.Win + gx : -1);
     }
-    constexpr int W_PT = (W_UNITS + 255) / 256;
+    constexpr int W_PT = (W_UNITS + NTHREADS - 1) / NTHREADS;
     const int nct32 = a.CoutPad / 32;
     const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.w);
     int w_off[W_PT];                                          // per-thread part of the weight unit index
 #pragma unroll
     for (int j = 0; j < W_PT; ++j) {
-        const int u = min(tid + 256 * j, W_UNITS - 1);
-        const int piece = u / (MT * 128), within = u - piece * (MT * 128);     // piece = (kstep, tap)
+        const int u = min(tid + NTHREADS * j, W_UNITS - 1);
+        const int piece = u / (MTB * 128), within = u - piece * (MTB * 128);   // piece = (kstep, tap)
         w_off[j] = piece * nct32 * 128 + within;
     }
     const size_t w_chunk_units = (size_t)TAPS * nct32 * 128;                   // units per 16-channel k-step
-    const size_t w_ct = (size_t)ct * MT * 128;
+    const size_t w_ct = (size_t)ct * MTB * 128;
 
     // PF = prefetch distance in chunks: PF register sets hold chunks in flight (set B only exists when PF == 2)
     float in_regA[PPT * GPT * 8], in_regB[PF == 2 ? PPT * GPT * 8 : 1];
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(ConvArgs a) {
             }                                                                                               \
         }                                                                                                   \
         _Pragma("unroll") for (int j = 0; j < W_PT; ++j) {                                                  \
-            const int u = tid + 256 * j;                                                                    \
+            const int u = tid + NTHREADS * j;                                                               \
             if (u < W_UNITS) *reinterpret_cast<u32x4*>(s_w + (size_t)u * 16) = w_reg[j];                    \
         }                                                                                                   \
     }
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(ConvArgs a) {
             F.b_lo[p] = *reinterpret_cast<const half8*>(s_in_lo + boff);                                    \
         }                                                                                                   \
         _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                    \
-            const unsigned char* wt = s_w + ((size_t)(((KSI) * TAPS + (T)) * MT + m) * 128 + lane) * 16;    \
+            const unsigned char* wt = s_w + ((size_t)(((KSI) * TAPS + (T)) * MTB + wave_g * MT + m) * 128 + lane) * 16; \
             F.a_hi[m] = *reinterpret_cast<const half8*>(wt);                                                \
             F.a_lo[m] = *reinterpret_cast<const half8*>(wt + 1024);                                         \
         }                                                                                                   \
@@ -203,14 +210,15 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(ConvArgs a) {
             acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_hi[m], F.b_hi[p], acc[m][p], 0, 0, 0);   \
         }
 
-#ifdef TCS_ASM_FETCH
     // Hand-pipelined operand fetch: inline-asm ds_read_b128 with counted s_waitcnt, so that the R = 2*MP + 2*MT reads of
     // step i+1 are in flight during the 3*MT*MP MFMAs of step i (hipcc puts compiler-visible ds_reads right in front of
-    // their consumer with lgkmcnt(0)).  This kernel has no static __shared__, so the dynamic segment starts at
+    // their consumer with lgkmcnt(0)).  Measured: MFMA phase 1,450 -> 925 cycles per chunk for one block per CU, and the
+    // narrow tiles (MT = 1) gain 5-12 %; the MT = 2 tiles are 5-8 % faster with the compiler's own schedule, so the
+    // choice follows MT.  This kernel has no static __shared__, so the dynamic segment starts at
     // __builtin_amdgcn_groupstaticsize().
     const unsigned lds_base = __builtin_amdgcn_groupstaticsize();
     const unsigned addr_b = lds_base + (unsigned)((half * IN_CH + wave * MP * STRIDE * IW + STRIDE * l31) * 16);
-    const unsigned addr_a = lds_base + (unsigned)(2 * IN_BYTES + lane * 16);
+    const unsigned addr_a = lds_base + (unsigned)(2 * IN_BYTES + (wave_g * MT * 128 + lane) * 16);
     // the immediate offset field is 16 bits; the (compile-time) part above 32 KB goes into the address register
 #define TCS_DSREAD(DST, ADDR, OFF) \
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"((ADDR) + (unsigned)((OFF) & ~0x7fff)), "i"((OFF) & 0x7fff) : "memory")
@@ -221,12 +229,12 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(ConvArgs a) {
             TCS_DSREAD(F.b_lo[p], addr_b, ((2 * (KSI)) * IN_CH + (STRIDE * p + (T) / KS) * IW + (T) % KS) * 16 + IN_BYTES); \
         }                                                                                                   \
         _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                    \
-            TCS_DSREAD(F.a_hi[m], addr_a, (((KSI) * TAPS + (T)) * MT + m) * 2048);                          \
-            TCS_DSREAD(F.a_lo[m], addr_a, (((KSI) * TAPS + (T)) * MT + m) * 2048 + 1024);                   \
+            TCS_DSREAD(F.a_hi[m], addr_a, (((KSI) * TAPS + (T)) * MTB + m) * 2048);                         \
+            TCS_DSREAD(F.a_lo[m], addr_a, (((KSI) * TAPS + (T)) * MTB + m) * 2048 + 1024);                  \
         }                                                                                                   \
     }
 #define TCS_WAIT_LGKM(N) { asm volatile("s_waitcnt lgkmcnt(%0)" :: "i"(N) : "memory"); __builtin_amdgcn_sched_barrier(0); }
-#define TCS_COMPUTE()                                                                                       \
+#define TCS_COMPUTE_ASM()                                                                                       \
     {                                                                                                       \
         constexpr int NSTEP = KSTEPS * TAPS, R = 2 * MP + 2 * MT;                                           \
         static_assert(R <= 15, "lgkmcnt field");                                                            \
@@ -241,10 +249,9 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(ConvArgs a) {
             }                                                                                               \
         }                                                                                                   \
     }
-#else
     // compute on the chunk that is in LDS; software pipeline over the KSTEPS*TAPS steps: the ds_reads of step i+1 are
     // in flight during the MFMAs of step i
-#define TCS_COMPUTE()                                                                                       \
+#define TCS_COMPUTE_C()                                                                                       \
     {                                                                                                       \
         constexpr int NSTEP = KSTEPS * TAPS;                                                                \
         Frag f0, f1;                                                                                        \
@@ -259,7 +266,8 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(ConvArgs a) {
         }                                                                                                   \
     }
 
-#endif
+#define TCS_COMPUTE() { if constexpr (MT == 1) { TCS_COMPUTE_ASM() } else { TCS_COMPUTE_C() } }
+
     const int nchunks = (a.Cin + KC - 1) / KC;
     TCS_GROUP_BASES(0)
     TCS_LOAD_CHUNK(in_regA, w_regA, 0)
@@ -312,7 +320,7 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(ConvArgs a) {
         }
 #ifdef TCS_CONV_STAMPS
         if (lane == 0) {
-            const size_t w_ = ((size_t)blockIdx.x * 4 + wave) % 16384;
+            const size_t w_ = ((size_t)blockIdx.x * 4 * WM + wave_all) % 16384;
             for (int q = 0; q < 5; ++q) tcs_conv_stamps[w_ * 8 + q] = acc_t[q];
             tcs_conv_stamps[w_ * 8 + 5] = nchunks;
         }
@@ -338,6 +346,11 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(ConvArgs a) {
         }
     }
 #undef TCS_COMPUTE
+#undef TCS_COMPUTE_ASM
+#undef TCS_COMPUTE_C
+#undef TCS_FETCH_ASM
+#undef TCS_DSREAD
+#undef TCS_WAIT_LGKM
 #undef TCS_LOAD_CHUNK
 #undef TCS_GROUP_BASES
 #undef TCS_STORE_CHUNK
@@ -352,8 +365,210 @@ __global__ __launch_bounds__(256) void k_conv_f16x3(ConvArgs a) {
         if (py >= H) continue;
         const size_t pix = (size_t)py * W + px;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) conv_epilogue_tile<EPI>(a, b, ct * NT + m * 32 + 4 * half, pix, HW, acc[m][p], a.w_unscale);
+        for (int m = 0; m < MT; ++m)
+            conv_epilogue_tile<EPI>(a, b, ct * NT + (wave_g * MT + m) * 32 + 4 * half, pix, HW, acc[m][p], a.w_unscale);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-specialised variant: 4 consumer waves (MFMA only) + NP producer waves (global loads, fp16 split, LDS stores) per
+// block, two LDS buffers, ONE barrier per chunk.  In k_conv_f16x3 every wave does all of a chunk's work in sequence
+// (issue loads -> MFMAs -> wait loads -> split + store -> barriers), ~3,000 cycles per chunk of which 864*MT are MFMA
+// (in-kernel stamps and phase-ablated builds, tools/conv_phases.py / tools/conv_ablate.sh): co-resident blocks run those
+// phases in lock step, so the phases add instead of overlapping.  Here the staging of chunk i+1 runs on other waves of
+// the same SIMDs while chunk i is multiplied, and a chunk costs max(MFMA, staging) instead of their sum.
+// Same tiling, LDS images and packed weights as k_conv_f16x3<KS, MT, 1, KSTEPS, EPI>; stride 1 only.
+template <int KS, int MT, int KSTEPS, int EPI, int NP>
+__global__ __launch_bounds__(256 + 64 * NP) void k_conv_f16x3_ws(ConvArgs a) {
+    constexpr int HALO = KS / 2, IH = 4 + KS - 1, IW = 32 + KS - 1, TAPS = KS * KS, IN_CH = IH * IW;
+    constexpr int NT = 32 * MT, KC = 16 * KSTEPS, NG = 2 * KSTEPS;
+    constexpr int IN_BYTES = NG * IN_CH * 16;                                  // one of {hi, lo}
+    constexpr int W_UNITS = KSTEPS * TAPS * MT * 2 * 64;                       // 16-byte units per chunk
+    constexpr int BUF_BYTES = 2 * IN_BYTES + W_UNITS * 16;
+    constexpr int NPT = 64 * NP;                                               // producer threads
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = blockIdx.x;
+    const int ct = bid % a.nct, patch = bid / a.nct;
+    const int b = blockIdx.y;
+    const int y0 = (patch / a.npx) * 4, x0 = (patch % a.npx) * 32;
+    const int H = a.H, W = a.W;
+    const size_t HW = (size_t)H * W;
+    const size_t HWi = (size_t)a.Hin * a.Win;
+    const int nchunks = (a.Cin + KC - 1) / KC;
+
+    if (wave_all >= 4) {
+        // ---------------- producers ----------------
+        const int ptid = tid - 256;
+        constexpr int PARTS = NPT / ((IN_CH <= 128) ? 128 : 256);
+        static_assert(PARTS >= 1 && NG % PARTS == 0, "producer threads must split the channel groups evenly");
+        constexpr int TPP = NPT / PARTS, PPT = (IN_CH + TPP - 1) / TPP, GPT = NG / PARTS;
+        const int part = PARTS == 1 ? 0 : __builtin_amdgcn_readfirstlane(ptid / TPP);
+        const int tpos = ptid - part * TPP;
+        int s_pix[PPT];                                           // pixel offset, -1 = zero padding, -2 = no slot
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int pos = tpos + TPP * k;
+            const int sr = pos / IW, sc = pos - sr * IW;
+            const int gy = y0 - HALO + sr, gx = x0 - HALO + sc;
+            s_pix[k] = pos >= IN_CH ? -2 : ((gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) ? gy * a.Win + gx : -1);
+        }
+        constexpr int W_PT = (W_UNITS + NPT - 1) / NPT;
+        const int nct32 = a.CoutPad / 32;
+        const u32x4* wsrc = reinterpret_cast<const u32x4*>(a.w);
+        int w_off[W_PT];
+#pragma unroll
+        for (int j = 0; j < W_PT; ++j) {
+            const int u = min(ptid + NPT * j, W_UNITS - 1);
+            const int piece = u / (MT * 128), within = u - piece * (MT * 128);
+            w_off[j] = piece * nct32 * 128 + within;
+        }
+        const size_t w_chunk_units = (size_t)TAPS * nct32 * 128;
+        const size_t w_ct = (size_t)ct * MT * 128;
+        float in_reg[PPT * GPT * 8];
+        u32x4 w_reg[W_PT];
+        gptr_t nbase[GPT];
+#define WS_GROUP_BASES(C0)                                                                                  \
+    _Pragma("unroll") for (int gi = 0; gi < GPT; ++gi)                                                      \
+        nbase[gi] = conv_src_ptr(a, b, min((C0) + (part * GPT + gi) * 8, max(a.Cin - 8, 0)), HWi);
+#define WS_LOAD(C0)                                                                                         \
+    {                                                                                                       \
+        const u32x4* wchunk = wsrc + (size_t)((C0) / 16) * w_chunk_units + w_ct;                            \
+        _Pragma("unroll") for (int j = 0; j < W_PT; ++j)                                                    \
+            w_reg[j] = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>(                   \
+                (gbytes_t)(const char*)wchunk + (unsigned)w_off[j] * 16u);                                  \
+        _Pragma("unroll") for (int gi = 0; gi < GPT; ++gi) {                                                \
+            const int g0 = (C0) + (part * GPT + gi) * 8;                                                    \
+            if (a.src_align8) {                                                                             \
+                gptr_t bj = nbase[gi];                                                                      \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                             \
+                    _Pragma("unroll") for (int k = 0; k < PPT; ++k)                                         \
+                        in_reg[(k * GPT + gi) * 8 + j] = bj[max(s_pix[k], 0)];                              \
+                    bj += HWi;                                                                              \
+                }                                                                                           \
+            } else {                                                                                        \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                             \
+                    gptr_t base = conv_src_ptr(a, b, min(g0 + j, a.Cin - 1), HWi);                          \
+                    _Pragma("unroll") for (int k = 0; k < PPT; ++k)                                         \
+                        in_reg[(k * GPT + gi) * 8 + j] = base[max(s_pix[k], 0)];                            \
+                }                                                                                           \
+            }                                                                                               \
+        }                                                                                                   \
+    }
+#define WS_STORE(BUF, C0)                                                                                   \
+    {                                                                                                       \
+        unsigned char* s_in_hi = lds8 + (BUF) * BUF_BYTES;                                                  \
+        unsigned char* s_in_lo = s_in_hi + IN_BYTES;                                                        \
+        unsigned char* s_w = s_in_hi + 2 * IN_BYTES;                                                        \
+        _Pragma("unroll") for (int k = 0; k < PPT; ++k) {                                                   \
+            if (s_pix[k] > -2) {                                                                            \
+                const bool pix_ok = s_pix[k] >= 0;                                                          \
+                _Pragma("unroll") for (int gi = 0; gi < GPT; ++gi) {                                        \
+                    const int grp = part * GPT + gi;                                                        \
+                    const int gq = (C0) + grp * 8;                                                          \
+                    half8 hi8, lo8;                                                                         \
+                    _Pragma("unroll") for (int j = 0; j < 8; j += 2) {                                      \
+                        half2_t h2, l2;                                                                     \
+                        const float x0_ = (pix_ok && gq + j < a.Cin) ? in_reg[(k * GPT + gi) * 8 + j] : 0.f;        \
+                        const float x1_ = (pix_ok && gq + j + 1 < a.Cin) ? in_reg[(k * GPT + gi) * 8 + j + 1] : 0.f; \
+                        split_f16x2(x0_, x1_, h2, l2);                                                      \
+                        hi8[j] = h2[0]; hi8[j + 1] = h2[1]; lo8[j] = l2[0]; lo8[j + 1] = l2[1];             \
+                    }                                                                                       \
+                    const size_t unit = (size_t)grp * IN_CH + tpos + TPP * k;                               \
+                    *reinterpret_cast<half8*>(s_in_hi + unit * 16) = hi8;                                   \
+                    *reinterpret_cast<half8*>(s_in_lo + unit * 16) = lo8;                                   \
+                }                                                                                           \
+            }                                                                                               \
+        }                                                                                                   \
+        _Pragma("unroll") for (int j = 0; j < W_PT; ++j) {                                                  \
+            const int u = ptid + NPT * j;                                                                   \
+            if (u < W_UNITS) *reinterpret_cast<u32x4*>(s_w + (size_t)u * 16) = w_reg[j];                    \
+        }                                                                                                   \
+    }
+        WS_GROUP_BASES(0)
+        WS_LOAD(0)
+        WS_GROUP_BASES(KC)
+        WS_STORE(0, 0)
+        if (nchunks > 1) {
+            WS_LOAD(KC)
+            WS_GROUP_BASES(2 * KC)
+        }
+        __syncthreads();                                          // chunk 0 is in buffer 0
+        for (int i = 0; i < nchunks; ++i) {
+            if (i + 1 < nchunks) {
+                WS_STORE((i + 1) & 1, (i + 1) * KC)               // buffer (i+1)&1 was last read in iteration i-1
+                if (i + 2 < nchunks) {
+                    WS_LOAD((i + 2) * KC)
+                    WS_GROUP_BASES((i + 3) * KC)
+                }
+            }
+            __syncthreads();
+        }
+#undef WS_GROUP_BASES
+#undef WS_LOAD
+#undef WS_STORE
+        return;
+    }
+
+    // ---------------- consumers: wave = patch row ----------------
+    const int wave = wave_all;
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+    // operand fetch: inline-asm ds_read_b128 with counted waits (see k_conv_f16x3); no static __shared__ in this kernel
+    const unsigned lds_base = __builtin_amdgcn_groupstaticsize();
+    const unsigned addr_b0 = lds_base + (unsigned)((half * IN_CH + wave * IW + l31) * 16);
+    const unsigned addr_a0 = lds_base + (unsigned)(2 * IN_BYTES + lane * 16);
+    struct Frag { half8 b_hi, b_lo, a_hi[MT], a_lo[MT]; };
+#define WS_DSREAD(DST, ADDR, OFF) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"((ADDR) + (unsigned)((OFF) & ~0x7fff)), "i"((OFF) & 0x7fff) : "memory")
+#define WS_FETCH(F, KSI, T)                                                                                 \
+    {                                                                                                       \
+        WS_DSREAD(F.b_hi, addr_b, ((2 * (KSI)) * IN_CH + ((T) / KS) * IW + (T) % KS) * 16);                 \
+        WS_DSREAD(F.b_lo, addr_b, ((2 * (KSI)) * IN_CH + ((T) / KS) * IW + (T) % KS) * 16 + IN_BYTES);      \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                    \
+            WS_DSREAD(F.a_hi[m], addr_a, (((KSI) * TAPS + (T)) * MT + m) * 2048);                           \
+            WS_DSREAD(F.a_lo[m], addr_a, (((KSI) * TAPS + (T)) * MT + m) * 2048 + 1024);                    \
+        }                                                                                                   \
+    }
+#define WS_WAIT(N) { asm volatile("s_waitcnt lgkmcnt(%0)" :: "i"(N) : "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define WS_MMA(F)                                                                                           \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                        \
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_lo[m], F.b_hi, acc[m], 0, 0, 0);                \
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_hi[m], F.b_lo, acc[m], 0, 0, 0);                \
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_hi[m], F.b_hi, acc[m], 0, 0, 0);                \
+    }
+    __syncthreads();                                              // chunk 0 is in buffer 0
+    for (int i = 0; i < nchunks; ++i) {
+        const unsigned boff = (i & 1) ? (unsigned)BUF_BYTES : 0u;
+        const unsigned addr_b = addr_b0 + boff, addr_a = addr_a0 + boff;
+        constexpr int NSTEP = KSTEPS * TAPS, R = 2 + 2 * MT;
+        Frag f0, f1;
+        WS_FETCH(f0, 0, 0)
+#pragma unroll
+        for (int st = 0; st < NSTEP; st += 2) {
+            if (st + 1 < NSTEP) { WS_FETCH(f1, (st + 1) / TAPS, (st + 1) % TAPS) WS_WAIT(R) } else WS_WAIT(0)
+            WS_MMA(f0)
+            if (st + 1 < NSTEP) {
+                if (st + 2 < NSTEP) { WS_FETCH(f0, (st + 2) / TAPS, (st + 2) % TAPS) WS_WAIT(R) } else WS_WAIT(0)
+                WS_MMA(f1)
+            }
+        }
+        __syncthreads();
+    }
+#undef WS_DSREAD
+#undef WS_FETCH
+#undef WS_WAIT
+#undef WS_MMA
+    const int px = x0 + l31, py = y0 + wave;
+    if (px >= W || py >= H) return;
+    const size_t pix = (size_t)py * W + px;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) conv_epilogue_tile<EPI>(a, b, ct * NT + m * 32 + 4 * half, pix, HW, acc[m], a.w_unscale);
 }
 
 // Buffer descriptor from wave-uniform inputs.  readfirstlane makes the uniformity provable to hipcc; without it every
@@ -588,18 +803,33 @@ __global__ __launch_bounds__(256) void k_pack_weight_f16x3(const float* __restri
     packed[u] = *reinterpret_cast<uint4*>(&v);
 }
 
-template <int KS, int MT, int MP, int KSTEPS, int EPI, int STRIDE = 1, int PF = 1>
+template <int KS, int MT, int MP, int KSTEPS, int EPI, int STRIDE = 1, int PF = 1, int WM = 1>
 static int launch_f16(ConvArgs& a, hipStream_t s) {
     constexpr int IH = STRIDE * 4 * MP + KS - STRIDE, IW = STRIDE * 32 + KS - STRIDE, TAPS = KS * KS;
-    const size_t lds = (size_t)2 * (2 * KSTEPS) * IH * IW * 16 + (size_t)KSTEPS * TAPS * MT * 2 * 1024;
-    auto kern = k_conv_f16x3<KS, MT, MP, KSTEPS, EPI, STRIDE, PF>;
+    const size_t lds = (size_t)2 * (2 * KSTEPS) * IH * IW * 16 + (size_t)KSTEPS * TAPS * MT * WM * 2 * 1024;
+    auto kern = k_conv_f16x3<KS, MT, MP, KSTEPS, EPI, STRIDE, PF, WM>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return TCS_ELAUNCH;
     }
     a.npatch = a.npx * tcs_cdiv(a.H, 4 * MP);
+    a.nct = (a.CoutPad / 32) / (MT * WM);
+    hipLaunchKernelGGL(kern, dim3(a.npatch * a.nct, a.B), dim3(256 * WM), lds, s, a);
+    return tcs_launch_status();
+}
+
+template <int KS, int MT, int KSTEPS, int EPI, int NP>
+static int launch_f16_ws(ConvArgs& a, hipStream_t s) {
+    constexpr int IH = 4 + KS - 1, IW = 32 + KS - 1, TAPS = KS * KS;
+    const size_t lds = 2 * ((size_t)2 * (2 * KSTEPS) * IH * IW * 16 + (size_t)KSTEPS * TAPS * MT * 2 * 1024);
+    auto kern = k_conv_f16x3_ws<KS, MT, KSTEPS, EPI, NP>;
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return TCS_ELAUNCH;
+    }
+    a.npatch = a.npx * tcs_cdiv(a.H, 4);
     a.nct = (a.CoutPad / 32) / MT;
-    hipLaunchKernelGGL(kern, dim3(a.npatch * a.nct, a.B), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(a.npatch * a.nct, a.B), dim3(256 + 64 * NP), lds, s, a);
     return tcs_launch_status();
 }
 
@@ -636,12 +866,34 @@ static int launch_f16_tile(ConvArgs& a, hipStream_t s) {
     if (force_mp) mp = force_mp == 2 ? 2 : 1;
     // TCS_F16_DB=1 selects the double-buffered / buffer-load pipeline (k_conv_f16x3_db).  Measured on MI355X it ties or
     // trails the single-buffer kernel on every layer shape of the model, so it is opt-in.
+    // Wave-specialised kernel (k_conv_f16x3_ws) for the layers that cannot fill the chip: with <= 1-2 blocks per CU the
+    // per-chunk latency chain of the plain kernel is exposed, and overlapping staging with the MFMAs gains 10-18 %
+    // (tools/bench_conv.py: 128->128 at 1/32 scale 15.9 -> 13.5 us, gru16.zr 57.6 -> 50.9 us); on full grids it ties or loses.
+    // TCS_F16_WS = 4 / 8 forces it (producer waves), -1 disables it.
+    static const int force_ws = env_int("TCS_F16_WS");
+    int use_ws = force_ws;
+    if (force_ws == 0 && KS == 3 && !force_mt && !force_mp) {
+        const long long blocks_mt1 = px_tiles * nct32;
+        use_ws = blocks_mt1 <= 200 ? 8 : (blocks_mt1 <= 400 ? 4 : 0);
+        if (use_ws) mt = 1;
+    }
+    if (use_ws > 0 && mp == 1 && force_ks != 2) {
+        if (KS == 1) {
+            if (use_ws == 8) return mt == 2 ? launch_f16_ws<1, 2, 4, EPI, 8>(a, s) : launch_f16_ws<1, 1, 4, EPI, 8>(a, s);
+            return mt == 2 ? launch_f16_ws<1, 2, 4, EPI, 4>(a, s) : launch_f16_ws<1, 1, 4, EPI, 4>(a, s);
+        }
+        if (use_ws == 8) return mt == 2 ? launch_f16_ws<3, 2, 1, EPI, 8>(a, s) : launch_f16_ws<3, 1, 1, EPI, 8>(a, s);
+        return mt == 2 ? launch_f16_ws<3, 2, 1, EPI, 4>(a, s) : launch_f16_ws<3, 1, 1, EPI, 4>(a, s);
+    }
     static const int use_db = env_int("TCS_F16_DB") == 1;
     if (use_db && mp == 1 && force_ks != 2 && a.w_bytes > 0) {
         if (KS == 1) return mt == 2 ? launch_f16_db<1, 2, 4, EPI>(a, s) : launch_f16_db<1, 1, 4, EPI>(a, s);
         return mt == 2 ? launch_f16_db<3, 2, 1, EPI>(a, s) : launch_f16_db<3, 1, 1, EPI>(a, s);
     }
     if (KS == 1) {
+        static const int force_wm1 = env_int("TCS_F16_WM");
+        if (force_wm1 == 2 && mp == 1 && nct32 % 2 == 0) return launch_f16<1, 1, 1, 4, EPI, 1, 1, 2>(a, s);
+        if (force_wm1 == 4 && mp == 1 && nct32 % 4 == 0) return launch_f16<1, 1, 1, 4, EPI, 1, 1, 4>(a, s);
         if (mt == 2) return mp == 2 ? launch_f16<1, 2, 2, 4, EPI>(a, s) : launch_f16<1, 2, 1, 4, EPI>(a, s);
         return mp == 2 ? launch_f16<1, 1, 2, 4, EPI>(a, s) : launch_f16<1, 1, 1, 4, EPI>(a, s);
     }
@@ -649,6 +901,11 @@ static int launch_f16_tile(ConvArgs& a, hipStream_t s) {
     if (ks == 2) {
         if (mt == 2) return mp == 2 ? launch_f16<3, 2, 2, 2, EPI>(a, s) : launch_f16<3, 2, 1, 2, EPI>(a, s);
         return mp == 2 ? launch_f16<3, 1, 2, 2, EPI>(a, s) : launch_f16<3, 1, 1, 2, EPI>(a, s);
+    }
+    static const int force_wm = env_int("TCS_F16_WM");
+    if (force_wm == 2 && mp == 1 && nct32 % 2 == 0) {          // 8 waves: 64 (MT=1) or 128 (MT=2) output channels per block
+        if (mt == 2 && nct32 % 4 == 0) return launch_f16<3, 2, 1, 1, EPI, 1, 1, 2>(a, s);
+        return launch_f16<3, 1, 1, 1, EPI, 1, 1, 2>(a, s);
     }
     if (mt == 2) return mp == 2 ? launch_f16<3, 2, 2, 1, EPI>(a, s) : launch_f16<3, 2, 1, 1, EPI>(a, s);
     if (mp == 2) return launch_f16<3, 1, 2, 1, EPI>(a, s);
