@@ -61,19 +61,23 @@ def build_model(dev):
 
 
 class ClipRunner:
-    """Steps through a device-resident clip, carrying the temporal state like evaluate_stereo.py:170-197."""
+    """Steps through device-resident clips, carrying the temporal state like evaluate_stereo.py:170-197.  Several
+    independent sequences can ride the batch dimension (--seqs-per-gpu); one step = one frame of each."""
 
-    def __init__(self, model, seq, dev, iters):
+    def __init__(self, model, seqs, dev, iters):
         from tcs_mi355.harness import InputPadder
-        self.model, self.iters, self.n = model, iters, len(seq.frames)
-        K_raw = torch.as_tensor(seq.K, device=dev)[None]
-        self.baseline = torch.tensor([seq.baseline], device=dev)
+        seqs = list(seqs) if isinstance(seqs, (list, tuple)) else [seqs]
+        self.model, self.iters, self.n = model, iters, len(seqs[0].frames)
+        K_raw = torch.stack([torch.as_tensor(q.K) for q in seqs]).to(dev)
+        self.baseline = torch.tensor([q.baseline for q in seqs], device=dev)
         self.frames = []
-        for fr in seq.frames:
-            i1, i2 = torch.as_tensor(fr.image1, device=dev)[None], torch.as_tensor(fr.image2, device=dev)[None]
+        for t in range(self.n):
+            i1 = torch.stack([torch.as_tensor(q.frames[t].image1) for q in seqs]).to(dev)
+            i2 = torch.stack([torch.as_tensor(q.frames[t].image2) for q in seqs]).to(dev)
             padder = InputPadder(i1.shape, divis_by=32)
             (i1, i2), K = padder.pad(i1, i2, K=K_raw)
-            self.frames.append((i1.contiguous(), i2.contiguous(), K, torch.as_tensor(fr.T, device=dev)[None]))
+            T = torch.stack([torch.as_tensor(q.frames[t].T) for q in seqs]).to(dev)
+            self.frames.append((i1.contiguous(), i2.contiguous(), K, T))
         self.t = 0
         self.state = None
         self.last = None
@@ -158,6 +162,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch kernels eagerly instead of replaying HIP graphs")
+    ap.add_argument("--seqs-per-gpu", type=int, default=1,
+                    help="independent sequences stacked on the batch dimension of every launch (default 1 = BASELINE configs[1])")
     a = ap.parse_args()
 
     from tcs_mi355 import dist as tdist
@@ -174,8 +180,10 @@ def main():
     log("building model + synthetic clip")
     model, W = build_model(dev)
     model.use_hip_graph = not a.eager
-    seq = synth.make_sequence(2000 + rank, n_frames=CLIP_LEN, height=HEIGHT, width=WIDTH, max_disp=MAX_DISP)
-    runner = ClipRunner(model, seq, dev, ITERS)
+    S = max(1, a.seqs_per_gpu)
+    seqs = [synth.make_sequence(2000 + rank * S + j, n_frames=CLIP_LEN, height=HEIGHT, width=WIDTH, max_disp=MAX_DISP) for j in range(S)]
+    seq = seqs[0]
+    runner = ClipRunner(model, seqs, dev, ITERS)
 
     from tcs_mi355 import ops
     probe = ops.LookupProbe(dev, slots=64)
@@ -201,7 +209,7 @@ def main():
     ops.LOOKUP_PROBE = None
 
     elapsed = tdist.max_over_ranks(elapsed)
-    total_pairs = a.steps * max(world, 1)
+    total_pairs = a.steps * S * max(world, 1)
     value = total_pairs / elapsed
 
     # accuracy of the synthetic run (random-init weights: parity, not quality, is what is checked)
@@ -218,7 +226,7 @@ def main():
         epe_vs_oracle = [round(e, 6) for e in epes]
 
     # the run's only collective: per-rank [frames, elapsed] (EPE statistics ride the same vector in eval runs)
-    vecs = tdist.gather_vectors(np.array([a.steps, elapsed], np.float64))
+    vecs = tdist.gather_vectors(np.array([a.steps * S, elapsed], np.float64))
 
     if rank == 0:
         line = {
@@ -226,8 +234,9 @@ def main():
             "n_gpus": max(world, 1), "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "contraction": CONTRACTION,
-            "config": {"workload": "BASELINE configs[1]: 640x480 synthetic sequence len=10, D=192, 32 iters, one sequence per GPU",
-                       "frames_per_rank": a.steps, "weights": "key-seeded synthetic (tcs_mi355.weights)",
+            "config": {"workload": "BASELINE configs[1]: 640x480 synthetic sequence len=10, D=192, 32 iters, "
+                                   + ("one sequence per GPU" if S == 1 else f"{S} independent sequences batched per GPU"),
+                       "frames_per_rank": a.steps * S, "seqs_per_gpu": S, "weights": "key-seeded synthetic (tcs_mi355.weights)",
                        "launch": "eager" if a.eager else "hip-graph replay"},
             "roofline": roof, "cpu_baseline": cpu, "epe_vs_oracle_first_frames": epe_vs_oracle,
             "ranks_frames": [int(v[0]) for v in vecs],

@@ -216,12 +216,18 @@ template <int R>
 __global__ __launch_bounds__(256) void k_corr_lookup(LookupArgs a) {
     const int lane = threadIdx.x & 63;
     const int level = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (a.stamps && threadIdx.x == 0) a.stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();      // first instruction; stored at the end
     const int HW = a.H * a.W;
-    const long long p = (long long)blockIdx.x * 64 + lane;
-    if (p >= (long long)a.B * HW) return;
-    const int b = (int)(p / HW);
-    const int hw = (int)(p - (long long)b * HW);
+    const unsigned total = (unsigned)a.B * (unsigned)HW;                      // host checks B*H*W < 2^31
+    const unsigned p_raw = blockIdx.x * 64u + (unsigned)lane;
+    // No early exit and no per-tap branches: an out-of-range lane works on the last pixel and only its stores are
+    // masked, every tap load is unconditional on a clamped address and zero-selected afterwards.  The kernel is three
+    // dependent memory round trips long (arguments -> coordinate -> taps -> stores); branches around the loads made hipcc
+    // fetch the arguments in four separate waits and issue each tap under its own exec mask.
+    const bool active = p_raw < total;
+    const unsigned p = active ? p_raw : total - 1;
+    const int b = (int)(p / (unsigned)HW);
+    const int hw = (int)(p - (unsigned)b * (unsigned)HW);
     const int h = hw / a.W, w1 = hw - h * a.W;
     const int radius = (R > 0) ? R : a.radius;
     const int taps = 2 * radius + 1;
@@ -237,37 +243,42 @@ __global__ __launch_bounds__(256) void k_corr_lookup(LookupArgs a) {
     const float* base = a.pyr[level] + ((size_t)(b * a.H + h) * Wl) * a.W + w1;
 
     float* o = a.out + ((size_t)b * 4 * taps + (size_t)level * taps) * HW + hw;
-    float prev;
-    {
-        const int j = j0;
-        int d = q - j;
-        d = d < 0 ? d + Wl : (d >= Wl ? d - Wl : d);
-        prev = (j >= 0 && j < Wl) ? base[(size_t)d * a.W] : 0.f;
-    }
     if (R > 0) {
         float v[2 * (R > 0 ? R : 1) + 2];
 #pragma unroll
-        for (int t = 1; t <= 2 * R + 1; ++t) {
+        for (int t = 0; t <= 2 * R + 1; ++t) {
             const int j = j0 + t;
+            const bool ok = j >= 0 && j < Wl;
+            int d = q - j;
+            d = d < 0 ? d + Wl : (d >= Wl ? d - Wl : d);   // ragged widths: q can equal Wl
+            d = ok ? d : 0;
+            const float val = base[(size_t)d * a.W];
+            v[t] = ok ? val : 0.f;
+        }
+        if (active) {
+#pragma unroll
+            for (int t = 0; t < 2 * R + 1; ++t) o[(size_t)t * HW] = (1.f - fr) * v[t] + fr * v[t + 1];
+        }
+    } else {
+        float prev;
+        {
+            const int j = j0;
             int d = q - j;
             d = d < 0 ? d + Wl : (d >= Wl ? d - Wl : d);
-            v[t] = (j >= 0 && j < Wl) ? base[(size_t)d * a.W] : 0.f;
+            prev = (j >= 0 && j < Wl) ? base[(size_t)d * a.W] : 0.f;
         }
-        v[0] = prev;
-#pragma unroll
-        for (int t = 0; t < 2 * R + 1; ++t) o[(size_t)t * HW] = (1.f - fr) * v[t] + fr * v[t + 1];
-    } else {
         for (int t = 0; t < taps; ++t) {
             const int j = j0 + t + 1;
             int d = q - j;
             d = d < 0 ? d + Wl : (d >= Wl ? d - Wl : d);
             const float nxt = (j >= 0 && j < Wl) ? base[(size_t)d * a.W] : 0.f;
-            o[(size_t)t * HW] = (1.f - fr) * prev + fr * nxt;
+            if (active) o[(size_t)t * HW] = (1.f - fr) * prev + fr * nxt;
             prev = nxt;
         }
     }
     if (a.stamps && lane == 0) {
         __builtin_amdgcn_s_waitcnt(0);      // this wave's stores have been issued and acknowledged
+        if (threadIdx.x == 0) a.stamps[2 * blockIdx.x] = t_start;
         atomicMax(&a.stamps[2 * blockIdx.x + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }
 }
@@ -339,6 +350,7 @@ int tcs_corr_lookup(const float* pyr0, const float* pyr1, const float* pyr2, con
                     tcs_stream_t stream) {
     if (!pyr0 || !pyr1 || !pyr2 || !pyr3 || !coords || !out) return TCS_EINVAL;
     if (B <= 0 || H <= 0 || W < 8 || radius < 0 || radius > 16) return TCS_EINVAL;
+    if ((long long)B * H * W >= 2147483647LL) return TCS_EINVAL;               // the kernel indexes pixels in 32 bits
     LookupArgs a;
     a.pyr[0] = pyr0; a.pyr[1] = pyr1; a.pyr[2] = pyr2; a.pyr[3] = pyr3;
     a.coords = coords; a.out = out; a.stamps = stamps; a.B = B; a.H = H; a.W = W; a.radius = radius;

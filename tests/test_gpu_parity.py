@@ -414,6 +414,24 @@ def test_graph_replay_full_size_many_frames(dev, model):
             assert epe(graphed[t], eager[t]) <= 1e-5, (rep, t)
 
 
+def test_batched_sequences_match_single(dev, model):
+    """Independent sequences stacked on the batch dimension (bench.py --seqs-per-gpu) must give what each gives alone:
+    every kernel indexes its batch element, per-sample poses / intrinsics / baselines included."""
+    import bench
+    from tcs_mi355 import synth
+    seqs = [synth.make_sequence(40 + j, n_frames=3, height=96, width=128, max_disp=32.0) for j in range(2)]
+
+    def run(group):
+        r = bench.ClipRunner(model, group, dev, 3)
+        return [r.step()["flow"].clone() for _ in range(3)]
+
+    both = run(seqs)
+    for j, q in enumerate(seqs):
+        alone = run([q])
+        for t in range(3):
+            assert epe(both[t][j:j + 1], alone[t]) <= 1e-5, (j, t)
+
+
 def test_stride2_deconv_instancenorm_vs_torch(dev):
     """The U-Net pieces moved off MIOpen: 3x3 stride-2 conv, ConvTranspose2d(4,2,1), InstanceNorm (+act, +addend)."""
     from tcs_mi355 import ops
