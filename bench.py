@@ -164,6 +164,8 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch kernels eagerly instead of replaying HIP graphs")
     ap.add_argument("--seqs-per-gpu", type=int, default=1,
                     help="independent sequences stacked on the batch dimension of every launch (default 1 = BASELINE configs[1])")
+    ap.add_argument("--batched-leg", type=int, default=4,
+                    help="after the timed run, also time this many sequences per launch (reported under batched_leg; 0/1 = skip)")
     a = ap.parse_args()
 
     from tcs_mi355 import dist as tdist
@@ -225,6 +227,36 @@ def main():
         cpu, epes = cpu_baseline(W, seq, gpu_preds, 2)
         epe_vs_oracle = [round(e, 6) for e in epes]
 
+    # extra leg (not `value`): the same clip with several independent sequences per launch.  One 640x480 sequence leaves
+    # most launches under-filled (300-600 workgroups, 5.9 MB per lookup); this shows what the kernels do when fed.
+    batched = None
+    if rank == 0 and world == 1 and S == 1 and a.batched_leg > 1:
+        Sb = a.batched_leg
+        log(f"batched leg: {Sb} sequences per launch")
+        seqs_b = [seq] + [synth.make_sequence(2000 + j, n_frames=CLIP_LEN, height=HEIGHT, width=WIDTH, max_disp=MAX_DISP)
+                          for j in range(1, Sb)]
+        runner_b = ClipRunner(model, seqs_b, dev, ITERS)
+        ops.LOOKUP_PROBE = probe_b = ops.LookupProbe(dev, slots=64)
+        snaps_b = []
+        with torch.no_grad():
+            for _ in range(2):
+                runner_b.step()
+            probe_b.reset()
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for _ in range(a.steps):
+                runner_b.step()
+                snaps_b.append(probe_b.buf.clone())
+                probe_b.reset()
+            torch.cuda.synchronize()
+            tb = time.perf_counter() - tb
+        roof_b = lookup_roofline(probe_b, snaps_b)
+        ops.LOOKUP_PROBE = None
+        batched = {"seqs_per_gpu": Sb, "value": round(a.steps * Sb / tb, 4), "unit": "stereo-pairs/s",
+                   "ms_per_step": round(1e3 * tb / a.steps, 3),
+                   "lookup": {k: roof_b[k] for k in ("achieved", "frac", "avg_launch_us", "algorithmic_bytes_per_launch")} if roof_b else None}
+        del runner_b
+
     # the run's only collective: per-rank [frames, elapsed] (EPE statistics ride the same vector in eval runs)
     vecs = tdist.gather_vectors(np.array([a.steps * S, elapsed], np.float64))
 
@@ -238,7 +270,7 @@ def main():
                                    + ("one sequence per GPU" if S == 1 else f"{S} independent sequences batched per GPU"),
                        "frames_per_rank": a.steps * S, "seqs_per_gpu": S, "weights": "key-seeded synthetic (tcs_mi355.weights)",
                        "launch": "eager" if a.eager else "hip-graph replay"},
-            "roofline": roof, "cpu_baseline": cpu, "epe_vs_oracle_first_frames": epe_vs_oracle,
+            "roofline": roof, "cpu_baseline": cpu, "epe_vs_oracle_first_frames": epe_vs_oracle, "batched_leg": batched,
             "ranks_frames": [int(v[0]) for v in vecs],
         }
         print(json.dumps(line), flush=True)

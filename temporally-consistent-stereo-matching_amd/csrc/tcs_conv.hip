@@ -137,24 +137,102 @@ __global__ __launch_bounds__(256) void k_conv_cin1(ConvArgs a) {
     constexpr int HALO = KS / 2, TAPS = KS * KS;
     const int b = blockIdx.y, H = a.H, W = a.W;
     const int HW = H * W;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= HW) return;
+    const int p_raw = blockIdx.x * 256 + threadIdx.x;
+    const bool active = p_raw < HW;
+    const int p = active ? p_raw : HW - 1;
     const int y = p / W, x = p - y * W;
     const float* s = a.src[0] + (size_t)b * HW;
+    // taps: unconditional loads on clamped coordinates, zero-selected afterwards (a "load or zero" branch per tap makes
+    // hipcc wait for each load in turn)
     float in[TAPS];
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
         const int yy = y + t / KS - HALO, xx = x + t % KS - HALO;
-        in[t] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? s[yy * W + xx] : 0.f;
+        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const float v = s[min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)];
+        in[t] = ok ? v : 0.f;
     }
-    const int co_lo = blockIdx.z * 16, co_hi = min(a.Cout, co_lo + 16);
-    for (int co = co_lo; co < co_hi; ++co) {
-        float v = 0.f;
+    // 16 output channels per block.z; their TAPS x 16 weights go through LDS and are read back as broadcasts
+    // (784 wave-uniform scalar loads for the 7x7 stem overflow the SGPR file and spill)
+    const int co_lo = blockIdx.z * 16;
+    __shared__ __attribute__((aligned(16))) float s_w[TAPS * 16];
+    for (int i = threadIdx.x; i < TAPS * 16; i += 256) s_w[i] = a.w[(size_t)(i >> 4) * a.CoutPad + co_lo + (i & 15)];
+    __syncthreads();
+    float acc[16];
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t) v = fmaf(a.w[(size_t)t * a.CoutPad + co], in[t], v);
-        v += a.bias ? a.bias[co] : 0.f;
-        if (a.add1) v += a.add1[((size_t)b * a.Cout + co) * HW + p];
-        a.out[((size_t)b * a.out_ctot + a.out_coff + co) * HW + p] = apply_act(v, a.act) * a.post_scale;
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(&s_w[t * 16 + c4 * 4]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c4 * 4 + c] = fmaf(w4[c], in[t], acc[c4 * 4 + c]);
+        }
+        // one filter row at a time: left alone, the scheduler hoists all TAPS*4 LDS reads above the FMAs and spills
+        if (t % KS == KS - 1) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+    }
+    if (!active) return;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int co = co_lo + c;
+        if (co < a.Cout) {
+            float v = acc[c] + (a.bias ? a.bias[co] : 0.f);
+            if (a.add1) v += a.add1[((size_t)b * a.Cout + co) * HW + p];
+            a.out[((size_t)b * a.out_ctot + a.out_coff + co) * HW + p] = apply_act(v, a.act) * a.post_scale;
+        }
+    }
+}
+
+// 7x7 stem on a 1-channel input (BasicMotionEncoder.convf1, update.py:113): 64 x 4 pixel tile per block, the tile
+// (+3 halo) and the block's 49 x 16 weights live in LDS, the filter rows run as a rolled loop so that nothing spills
+// (fully unrolled, the 196 weight reads were hoisted and spilled to scratch).
+__global__ __launch_bounds__(256) void k_conv7x7_cin1(ConvArgs a) {
+    constexpr int KS = 7, HALO = 3, TW = 64, TH = 4, IW = TW + 2 * HALO, IH = TH + 2 * HALO;
+    __shared__ float s_in[IH * IW];
+    __shared__ __attribute__((aligned(16))) float s_w[KS * KS * 16];
+    const int b = blockIdx.y, H = a.H, W = a.W, HW = H * W;
+    const int ntx = (W + TW - 1) / TW;
+    const int tx0 = (blockIdx.x % ntx) * TW, ty0 = (blockIdx.x / ntx) * TH;
+    const int co_lo = blockIdx.z * 16;
+    const float* s = a.src[0] + (size_t)b * HW;
+    for (int i = threadIdx.x; i < IH * IW; i += 256) {
+        const int r = i / IW, c = i - r * IW;
+        const int yy = ty0 - HALO + r, xx = tx0 - HALO + c;
+        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        const float v = s[min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)];
+        s_in[i] = ok ? v : 0.f;
+    }
+    for (int i = threadIdx.x; i < KS * KS * 16; i += 256) s_w[i] = a.w[(size_t)(i >> 4) * a.CoutPad + co_lo + (i & 15)];
+    __syncthreads();
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+#pragma unroll 1
+    for (int ty = 0; ty < KS; ++ty) {
+#pragma unroll
+        for (int tx = 0; tx < KS; ++tx) {
+            const float v = s_in[(ly + ty) * IW + lx + tx];
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(&s_w[(ty * KS + tx) * 16 + c4 * 4]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c4 * 4 + c] = fmaf(w4[c], v, acc[c4 * 4 + c]);
+            }
+        }
+    }
+    const int x = tx0 + lx, y = ty0 + ly;
+    if (x >= W || y >= H) return;
+    const int p = y * W + x;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int co = co_lo + c;
+        if (co < a.Cout) {
+            float v = acc[c] + (a.bias ? a.bias[co] : 0.f);
+            if (a.add1) v += a.add1[((size_t)b * a.Cout + co) * HW + p];
+            a.out[((size_t)b * a.out_ctot + a.out_coff + co) * HW + p] = apply_act(v, a.act) * a.post_scale;
+        }
     }
 }
 
@@ -270,7 +348,10 @@ int tcs_conv2d(const tcs_conv_desc* d, tcs_stream_t stream) {
             const dim3 grid(tcs_cdiv((long long)d->H * d->W, 256), d->B, tcs_cdiv(d->Cout, 16));
             if (d->ksize == 1) hipLaunchKernelGGL(k_conv_cin1<1>, grid, dim3(256), 0, s, a);
             else if (d->ksize == 3) hipLaunchKernelGGL(k_conv_cin1<3>, grid, dim3(256), 0, s, a);
-            else if (d->ksize == 7) hipLaunchKernelGGL(k_conv_cin1<7>, grid, dim3(256), 0, s, a);
+            else if (d->ksize == 7) {
+                const dim3 g7(tcs_cdiv(d->W, 64) * tcs_cdiv(d->H, 4), d->B, tcs_cdiv(d->Cout, 16));
+                hipLaunchKernelGGL(k_conv7x7_cin1, g7, dim3(256), 0, s, a);
+            }
             else return TCS_EUNSUPPORTED;
             return tcs_launch_status();
         }
