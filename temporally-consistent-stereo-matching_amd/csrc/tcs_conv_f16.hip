@@ -55,10 +55,13 @@ __device__ __forceinline__ void split_f16x2(float x0, float x1, half2_t& hi, hal
 // fp16 split, LDS traffic) against 27*MT*MP MFMAs per wave: with 4 waves the block is issue-bound at 4-5x the MFMA time
 // (measured with in-kernel stamps, tools/conv_phases.py).  WM = 2 halves the staging work per wave and doubles the
 // waves that share one LDS image.
-template <int KS, int MT, int MP, int KSTEPS, int EPI, int STRIDE = 1, int PF = 1, int WM = 1>
-__global__ __launch_bounds__(256 * WM) void k_conv_f16x3(ConvArgs a) {
-    constexpr int NTHREADS = 256 * WM, MTB = MT * WM;                          // MTB: cout tiles per block
-    constexpr int HALO = KS / 2, PR = 4 * MP, IH = STRIDE * PR + KS - STRIDE, IW = STRIDE * 32 + KS - STRIDE, TAPS = KS * KS,
+// ROWS = waves along the patch rows (patch = ROWS*MP rows): 5 instead of 4 turns the 600- and 300-workgroup grids of the
+// 1/4-scale layers (2.3 and 1.2 workgroups per CU: some CUs carry one more than the others for the whole kernel) into
+// 480 and 240 (at most 2 / 1 per CU).
+template <int KS, int MT, int MP, int KSTEPS, int EPI, int STRIDE = 1, int PF = 1, int WM = 1, int ROWS = 4>
+__global__ __launch_bounds__(64 * ROWS * WM) void k_conv_f16x3(ConvArgs a) {
+    constexpr int NTHREADS = 64 * ROWS * WM, MTB = MT * WM;                    // MTB: cout tiles per block
+    constexpr int HALO = KS / 2, PR = ROWS * MP, IH = STRIDE * PR + KS - STRIDE, IW = STRIDE * 32 + KS - STRIDE, TAPS = KS * KS,
                   IN_CH = IH * IW;
     constexpr int NT = 32 * MTB, KC = 16 * KSTEPS, NG = 2 * KSTEPS;           // NG: 8-channel groups per chunk
     constexpr int IN_BYTES = NG * IN_CH * 16;                                  // one of {hi, lo}
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256 * WM) void k_conv_f16x3(ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = wave_all & 3, wave_g = wave_all >> 2;                    // patch row, cout group
+    const int wave = wave_all % ROWS, wave_g = wave_all / ROWS;               // patch row, cout group
     const int bid = blockIdx.x;
     const int ct = bid % a.nct, patch = bid / a.nct;
     const int b = blockIdx.y;
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256 * WM) void k_conv_f16x3(ConvArgs a) {
     // A thread owns PPT halo positions and, for each, GPT of the chunk's NG 8-channel groups.  The group index
     // is uniform across a wave (across the block when PARTS == 1), so the per-chunk base pointer of a group is
     // computed on the scalar unit and every load is `global_load_dword v, v_pixel_offset, s[base]`.
-    constexpr int PARTS = NTHREADS / ((IN_CH <= 128) ? 128 : 256);   // thread groups that split the channel groups
+    constexpr int PARTS = (NTHREADS / ((IN_CH <= 128) ? 128 : 256)) > 0 ? (NTHREADS / ((IN_CH <= 128) ? 128 : 256)) : 1;
     constexpr int TPP = NTHREADS / PARTS;                     // threads per part
     constexpr int PPT = (IN_CH + TPP - 1) / TPP;              // positions per thread
     constexpr int GPT = NG / PARTS;                           // groups per thread
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(256 * WM) void k_conv_f16x3(ConvArgs a) {
         }
 #ifdef TCS_CONV_STAMPS
         if (lane == 0) {
-            const size_t w_ = ((size_t)blockIdx.x * 4 * WM + wave_all) % 16384;
+            const size_t w_ = ((size_t)blockIdx.x * ROWS * WM + wave_all) % 16384;
             for (int q = 0; q < 5; ++q) tcs_conv_stamps[w_ * 8 + q] = acc_t[q];
             tcs_conv_stamps[w_ * 8 + 5] = nchunks;
         }
@@ -803,18 +806,18 @@ __global__ __launch_bounds__(256) void k_pack_weight_f16x3(const float* __restri
     packed[u] = *reinterpret_cast<uint4*>(&v);
 }
 
-template <int KS, int MT, int MP, int KSTEPS, int EPI, int STRIDE = 1, int PF = 1, int WM = 1>
+template <int KS, int MT, int MP, int KSTEPS, int EPI, int STRIDE = 1, int PF = 1, int WM = 1, int ROWS = 4>
 static int launch_f16(ConvArgs& a, hipStream_t s) {
-    constexpr int IH = STRIDE * 4 * MP + KS - STRIDE, IW = STRIDE * 32 + KS - STRIDE, TAPS = KS * KS;
+    constexpr int IH = STRIDE * ROWS * MP + KS - STRIDE, IW = STRIDE * 32 + KS - STRIDE, TAPS = KS * KS;
     const size_t lds = (size_t)2 * (2 * KSTEPS) * IH * IW * 16 + (size_t)KSTEPS * TAPS * MT * WM * 2 * 1024;
-    auto kern = k_conv_f16x3<KS, MT, MP, KSTEPS, EPI, STRIDE, PF, WM>;
+    auto kern = k_conv_f16x3<KS, MT, MP, KSTEPS, EPI, STRIDE, PF, WM, ROWS>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return TCS_ELAUNCH;
     }
-    a.npatch = a.npx * tcs_cdiv(a.H, 4 * MP);
+    a.npatch = a.npx * tcs_cdiv(a.H, ROWS * MP);
     a.nct = (a.CoutPad / 32) / (MT * WM);
-    hipLaunchKernelGGL(kern, dim3(a.npatch * a.nct, a.B), dim3(256 * WM), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(a.npatch * a.nct, a.B), dim3(64 * ROWS * WM), lds, s, a);
     return tcs_launch_status();
 }
 
@@ -870,6 +873,16 @@ static int launch_f16_tile(ConvArgs& a, hipStream_t s) {
     // per-chunk latency chain of the plain kernel is exposed, and overlapping staging with the MFMAs gains 10-18 %
     // (tools/bench_conv.py: 128->128 at 1/32 scale 15.9 -> 13.5 us, gru16.zr 57.6 -> 50.9 us); on full grids it ties or loses.
     // TCS_F16_WS = 4 / 8 forces it (producer waves), -1 disables it.
+    // 5-row patches when they balance the grid better: efficiency = workgroups / (256 * rounds of one-per-CU)
+    static const int force_rows = env_int("TCS_F16_ROWS");      // 4 / 5 force, 0 = by grid balance
+    if (KS == 3 && !force_mp && force_ks != 2 && force_rows != 4) {
+        const long long wg4 = (long long)a.npx * tcs_cdiv(a.H, 4) * a.B * (nct32 / mt), wg5 = (long long)a.npx * tcs_cdiv(a.H, 5) * a.B * (nct32 / mt);
+        const double e4 = (double)wg4 / (256.0 * ((wg4 + 255) / 256)), e5 = (double)wg5 / (256.0 * ((wg5 + 255) / 256));
+        // measured (tools/bench_conv.py): 32-channel tiles gain 4-8 % (gru08.q 83 -> 77 us, 128->128 32.3 -> 30.9 us), the
+        // 64-channel tiles lose 20 % (gru08.zr 135 -> 163 us), so the automatic choice is limited to MT = 1
+        if (force_rows == 5) return mt == 2 ? launch_f16<3, 2, 1, 1, EPI, 1, 1, 1, 5>(a, s) : launch_f16<3, 1, 1, 1, EPI, 1, 1, 1, 5>(a, s);
+        if (mt == 1 && e5 > e4 + 0.05 && wg4 > 400 && wg4 <= 768) return launch_f16<3, 1, 1, 1, EPI, 1, 1, 1, 5>(a, s);
+    }
     static const int force_ws = env_int("TCS_F16_WS");
     int use_ws = force_ws;
     if (force_ws == 0 && KS == 3 && !force_mt && !force_mp) {
