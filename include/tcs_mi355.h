@@ -185,6 +185,7 @@ int tcs_resize_bilinear(const float* x, int B, int C, int H, int W, int Ho, int 
 #define TCS_ACT_SIGMOID 2
 #define TCS_ACT_TANH 3
 #define TCS_ACT_LEAKY 4          /* LeakyReLU(0.01) */
+#define TCS_ACT_RELU_ADD_RELU 5  /* relu(relu(v) + addend): the tail of a residual block (extractor.py:44-58); needs addend */
 
 #define TCS_EPI_LINEAR 0         /* out = act(conv + bias + addend) * post_scale                   */
 #define TCS_EPI_GRU_ZR 1         /* first half: z = sigmoid(. + cz) -> out; second half: r = sigmoid(. + cr), out2 = r*h */

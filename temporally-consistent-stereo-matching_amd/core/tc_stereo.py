@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from core.corr import CorrBlock1D
-from core.extractor import BasicEncoder, MultiBasicEncoder, ResidualBlock
+from core.extractor import BasicEncoder, MultiBasicEncoder, ResidualBlock, hip_head
 from core.update import (BasicMultiUpdateBlock, DispGradPredictor, DispRefine, DisparityCompletor, HiddenstateUpdater,
                          Lightfuse, hip_conv)
 from core.utils.utils import coords_grid
@@ -82,7 +82,7 @@ class TCStereo(nn.Module):
         a = self.args
         if a.shared_backbone:
             *cnet_list, trunk = self.cnet(torch.cat((image1, image2), 0), dual_inp=True, num_layers=a.n_gru_layers)
-            fmap1, fmap2 = self.conv2(trunk).split(trunk.shape[0] // 2, 0)
+            fmap1, fmap2 = hip_head(self.conv2, trunk).split(trunk.shape[0] // 2, 0)
         else:
             cnet_list = self.cnet(image1, num_layers=a.n_gru_layers)
             fmap1, fmap2 = self.fnet([image1, image2])

@@ -311,6 +311,7 @@ int tcs_conv2d(const tcs_conv_desc* d, tcs_stream_t stream) {
     const int stride = d->stride == 2 ? 2 : 1;
     a.Hin = d->H; a.Win = d->W;
     a.B = d->B; a.H = stride == 2 ? (d->H - 1) / 2 + 1 : d->H; a.W = stride == 2 ? (d->W - 1) / 2 + 1 : d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.CoutPad = round_up(d->Cout, nt);
+    if (d->act == TCS_ACT_RELU_ADD_RELU && (!d->addend || d->epilogue != TCS_EPI_LINEAR || d->Cin == 1)) return TCS_EINVAL;
     a.act = d->act; a.post_scale = d->post_scale;
     a.add1 = d->addend; a.add2 = d->addend2; a.h = d->h; a.z = d->z;
     a.keep_z = d->blend_keep_z; a.hidden = 0;

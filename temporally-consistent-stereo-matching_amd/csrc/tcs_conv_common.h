@@ -91,16 +91,18 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, int b, int
         for (int r = 0; r < 16; ++r) v[r] += a.bias[cc[r]];
     }
     if (EPI == TCS_EPI_LINEAR) {
+        const bool late = a.act == TCS_ACT_RELU_ADD_RELU;          // relu(relu(v) + addend)
         if (a.add1) {
             float t[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) t[r] = a.add1[((size_t)b * a.Cout + cc[r]) * HW + pix];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] += t[r];
+            for (int r = 0; r < 16; ++r) v[r] = (late ? fmaxf(v[r], 0.f) : v[r]) + t[r];
         }
+        const int act = late ? TCS_ACT_RELU : a.act;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            if (ok[r]) a.out[((size_t)b * a.out_ctot + a.out_coff + cc[r]) * HW + pix] = apply_act(v[r], a.act) * a.post_scale;
+            if (ok[r]) a.out[((size_t)b * a.out_ctot + a.out_coff + cc[r]) * HW + pix] = apply_act(v[r], act) * a.post_scale;
     } else if (EPI == TCS_EPI_GRU_ZR) {
         // channel < hidden: z = sigmoid(. + cz) -> out ; else r = sigmoid(. + cr), out2 = r * h
         size_t o[16];

@@ -11,7 +11,7 @@ import torch
 
 from . import native as nv
 
-ACT = {"none": 0, "relu": 1, "sigmoid": 2, "tanh": 3, "leaky": 4}
+ACT = {"none": 0, "relu": 1, "sigmoid": 2, "tanh": 3, "leaky": 4, "relu_add_relu": 5}
 EPI_LINEAR, EPI_GRU_ZR, EPI_GRU_Q = 0, 1, 2
 
 

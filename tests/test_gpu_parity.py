@@ -301,7 +301,9 @@ def test_e2e_c1_golden(dev, e2e_golden, model):
     assert tuple(out["flow"].shape) == (1, 1, 256, 320)
     assert epe(out["flow_q"], e2e_golden["c1_flow_q"]) <= 1e-4
     assert epe(out["flow"], e2e_golden["c1_flow"]) <= 1e-4
-    assert maxdiff(out["fmap1"].sum((2, 3)), e2e_golden["c1_fmap1_sum"]) <= 1e-2
+    # per-channel sums over 5,120 pixels: 1e-2 absolute plus 1e-5 of the largest sum (fp32 summation-order noise)
+    ref_sum = T(e2e_golden["c1_fmap1_sum"])
+    assert maxdiff(out["fmap1"].sum((2, 3)), ref_sum) <= 1e-2 + 1e-5 * float(ref_sum.abs().max())
     assert float(out["flow"].max()) <= 0.0
 
 
@@ -412,6 +414,22 @@ def test_graph_replay_full_size_many_frames(dev, model):
         run_sequence(model, seq, iters=2, device=dev, collect=graphed)
         for t in range(4):
             assert epe(graphed[t], eager[t]) <= 1e-5, (rep, t)
+
+
+@pytest.mark.parametrize("kind", ["none", "instance"])
+@pytest.mark.parametrize("cin,cout,stride", [(64, 64, 1), (64, 96, 2), (96, 128, 1)])
+def test_extractor_block_vs_torch(dev, kind, cin, cout, stride, monkeypatch):
+    """ResidualBlock (extractor.py:5-58) on tcs_conv2d / tcs_instance_norm against the same module on PyTorch ops."""
+    from core.extractor import ResidualBlock
+    torch.manual_seed(3)
+    blk = ResidualBlock(cin, cout, kind, stride).to(dev).eval()
+    x = torch.randn(2, cin, 37, 70, device=dev)          # ragged size; negative inputs exercise the final ReLU
+    with torch.no_grad():
+        got = blk(x)
+        monkeypatch.setenv("TCS_MI355_EXTRACTOR", "torch")
+        ref = blk(x)
+    assert got.shape == ref.shape
+    assert maxdiff(got, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
 def test_batched_sequences_match_single(dev, model):
