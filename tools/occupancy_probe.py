@@ -11,7 +11,8 @@ dev = torch.device("cuda:0")
 gen = torch.Generator().manual_seed(0)
 w = (torch.randn(256, 384, 3, 3, generator=gen) * 0.02).to(dev)
 pc = ops.pack_conv(w, torch.zeros(256, device=dev), "f16x3")
-for rows4 in (3, 6, 9, 12, 13, 16, 19, 22, 25, 26, 28, 30, 32, 36, 38, 39, 42, 48, 51, 52, 56, 64, 77, 78, 90, 102, 103, 116, 128):
+ROWS4 = tuple(int(v) for v in os.environ.get("PROBE_ROWS4", "3,6,9,12,13,16,19,22,25,26,28,30,32,36,38,39,42,48,51,52,56,64,77,78,90,102,103,116,128").split(","))
+for rows4 in ROWS4:
     H, W = 4 * rows4, 160
     xs = [torch.randn(1, 128, H, W, generator=gen).to(dev) for _ in range(3)]
     h = torch.randn(1, 128, H, W, generator=gen).to(dev)
