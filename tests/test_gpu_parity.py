@@ -105,6 +105,30 @@ def test_corr_lookup_integer_coords_property(dev):
     assert (centre[~inside.to(dev)] == 0).all()
 
 
+def test_corr_lookup_extreme_coords(dev, oracle):
+    """Edge cases of the sampler (corr.py:33-52 / bilinear_sampler zero padding): coordinates far outside the row on
+    either side give exact zeros, half-in windows match the oracle, huge magnitudes stay defined (no int overflow)."""
+    from tcs_mi355 import ops
+    B, Cc, H, W = 1, 32, 6, 40
+    gen = torch.Generator().manual_seed(9)
+    f1, f2 = torch.randn(B, Cc, H, W, generator=gen), torch.randn(B, Cc, H, W, generator=gen)
+    p = ops.corr_build(D(f1, dev), D(f2, dev))
+    pyr = oracle.corr_pyramid(oracle.corr_volume(f1, f2))
+    coords = torch.zeros(B, 1, H, W)
+    coords[0, 0, 0] = -1000.0
+    coords[0, 0, 1] = 1000.0
+    coords[0, 0, 2] = torch.linspace(-6.0, 3.0, W)           # windows straddling the left border
+    coords[0, 0, 3] = torch.linspace(W - 4.0, W + 6.0, W)    # ... and the right border
+    coords[0, 0, 4] = 3.0e9                                  # beyond int32
+    coords[0, 0, 5] = -3.0e9
+    got = ops.corr_lookup(p, D(coords, dev), 4)
+    assert torch.isfinite(got).all()
+    for row in (0, 1, 4, 5):
+        assert (got[0, :, row] == 0).all(), row
+    want = oracle.corr_lookup(pyr, coords, 4)
+    assert maxdiff(got[0, :, 2:4], want[0, :, 2:4]) <= 1e-5
+
+
 # ------------------------------------------------------------------------------------------------
 # temporal warp
 # ------------------------------------------------------------------------------------------------
@@ -326,6 +350,22 @@ def test_e2e_c2_golden(dev, e2e_golden, model):
     fr = synth.make_sequence(2000, n_frames=1).frames[0]
     out = model(D(fr.image1, dev)[None], D(fr.image2, dev)[None], iters=32, test_mode=True)
     assert epe(out["flow_q"], e2e_golden["c2_flow_q"]) <= 1e-3
+
+
+def test_e2e_kitti_shape_vs_oracle(dev, oracle, synth_weights, model):
+    """BASELINE config 5's shape (KITTI raw 1242x375, padded to 1248x384 by InputPadder): first frame + one temporal
+    frame, 2 iterations, HIP against the CPU oracle through the evaluation harness (un-padded outputs)."""
+    from tcs_mi355 import synth
+    from tcs_mi355.harness import run_sequence
+    seq = synth.make_sequence(5, n_frames=2, height=375, width=1242, max_disp=192.0)
+    got, want = [], []
+    run_sequence(model, seq, iters=2, device=dev, collect=got)
+    torch.set_num_threads(16)
+    run_sequence(lambda a, b, **kw: oracle.tc_stereo_forward(synth_weights, a, b, iters=kw["iters"], params=kw["params"]), seq, iters=2,
+                 device=torch.device("cpu"), collect=want)
+    for t in range(2):
+        assert tuple(got[t].shape[-2:]) == (375, 1242)
+        assert epe(got[t], want[t]) <= 1e-4, t
 
 
 def test_no_cpu_fallback(dev, model):
