@@ -29,7 +29,10 @@ SHAPES = [  # name, (cins...), cout, k, H, W, epilogue
 ]
 maths = sys.argv[1].split(",") if len(sys.argv) > 1 else ["f16x3", "f32"]
 gen = torch.Generator().manual_seed(0)
+ONLY = [t for t in os.environ.get("BENCH_ONLY", "").split(",") if t]
 for name, cins, cout, k, H, W, epi in SHAPES:
+    if ONLY and name not in ONLY:
+        continue
     cin = sum(cins)
     w = (torch.randn(cout, cin, k, k, generator=gen) * 0.02).to(dev)
     b = torch.zeros(cout, device=dev)
