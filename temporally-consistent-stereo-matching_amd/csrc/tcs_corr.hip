@@ -212,8 +212,15 @@ struct LookupArgs {
     int B, H, W, radius;
 };
 
+// Plain scalar parameters (not a struct): hipcc can then preload the first 16 kernarg dwords into SGPRs at wave launch
+// (-mllvm -amdgpu-kernarg-preload-count), which takes the argument fetch off this latency-bound kernel's critical path.
 template <int R>
-__global__ __launch_bounds__(256) void k_corr_lookup(LookupArgs a) {
+__global__ __launch_bounds__(256) void k_corr_lookup(const float* __restrict__ pyr0, const float* __restrict__ pyr1,
+                                                     const float* __restrict__ pyr2, const float* __restrict__ pyr3,
+                                                     const float* __restrict__ coords_p, float* __restrict__ out_p,
+                                                     int Bn, int Hn, int Wn, int radius_n, unsigned long long* stamps_p) {
+    struct { const float* coords; float* out; unsigned long long* stamps; int B, H, W, radius; } a =
+        {coords_p, out_p, stamps_p, Bn, Hn, Wn, radius_n};
     const int lane = threadIdx.x & 63;
     const int level = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();      // first instruction; stored at the end
@@ -240,7 +247,9 @@ __global__ __launch_bounds__(256) void k_corr_lookup(LookupArgs a) {
     const float fr = x - x0;
     const int j0 = (int)x0 - radius;
     const int q = w1 >> level;
-    const float* base = a.pyr[level] + ((size_t)(b * a.H + h) * Wl) * a.W + w1;
+    // wave-uniform select (a local array indexed by `level` would live in scratch)
+    const float* pyr_l = level == 0 ? pyr0 : (level == 1 ? pyr1 : (level == 2 ? pyr2 : pyr3));
+    const float* base = pyr_l + ((size_t)(b * a.H + h) * Wl) * a.W + w1;
 
     float* o = a.out + ((size_t)b * 4 * taps + (size_t)level * taps) * HW + hw;
     if (R > 0) {
@@ -356,9 +365,11 @@ int tcs_corr_lookup(const float* pyr0, const float* pyr1, const float* pyr2, con
     a.coords = coords; a.out = out; a.stamps = stamps; a.B = B; a.H = H; a.W = W; a.radius = radius;
     const int blocks = tcs_cdiv((long long)B * H * W, 64);
     if (radius == 4)
-        hipLaunchKernelGGL(k_corr_lookup<4>, dim3(blocks), dim3(256), 0, tcs_stream(stream), a);
+        hipLaunchKernelGGL(k_corr_lookup<4>, dim3(blocks), dim3(256), 0, tcs_stream(stream), pyr0, pyr1, pyr2, pyr3, coords, out, B, H, W,
+                           radius, stamps);
     else
-        hipLaunchKernelGGL(k_corr_lookup<0>, dim3(blocks), dim3(256), 0, tcs_stream(stream), a);
+        hipLaunchKernelGGL(k_corr_lookup<0>, dim3(blocks), dim3(256), 0, tcs_stream(stream), pyr0, pyr1, pyr2, pyr3, coords, out, B, H, W,
+                           radius, stamps);
     return tcs_launch_status();
 }
 
