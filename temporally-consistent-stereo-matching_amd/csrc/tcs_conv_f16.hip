@@ -1041,65 +1041,69 @@ __global__ __launch_bounds__(IN_T) void k_instance_norm(const float* __restrict_
 }
 
 // 3x3 convolution with ONE output channel (FlowHead.conv2 256->1, update.py:13): a matrix-core tile would waste 31
-// of 32 output columns, so this is a plain reduction: a wave owns 64 consecutive pixels, lanes = pixels, the 8 waves
-// of a block split the input channels and combine through LDS.  Weights are wave-uniform scalar loads.  The channel
-// loop is unrolled by 8 (72 independent loads in flight per lane): rolled, every channel waited for its own loads and
-// the kernel was one L2 round trip per channel long (27 us for 256 channels at 120x160).
+// of 32 output columns, so this is a plain reduction.  A wave owns 62 consecutive output pixels of one row and loads 64
+// columns (one halo column on each side): the left / right taps come from the neighbouring lanes (DPP row shifts), so a
+// channel costs 3 loads per lane instead of 9 — the kernel was L1-bandwidth bound (177 MB through L1 for a 19.7 MB
+// input).  The 8 waves of a block split the input channels and combine through LDS; weights are wave-uniform scalar
+// loads; the channel loop is unrolled by 8 (24 independent loads in flight per lane).
 #define C1_WAVES 8
+#define C1_PX 62
 __global__ __launch_bounds__(64 * C1_WAVES) void k_conv3x3_cout1(const float* __restrict__ x, const float* __restrict__ w /*[Cin][9]*/,
                                                                  const float* __restrict__ bias, int Cin, int H, int W,
                                                                  float* __restrict__ out) {
     __shared__ float part[C1_WAVES][64];
-    const int b = blockIdx.y, HW = H * W;
+    const int b = blockIdx.z, HW = H * W;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int p = blockIdx.x * 64 + lane;
-    const int pc = min(p, HW - 1);
-    const int y = pc / W, xx = pc - y * W;
-    int off[9];
-    bool ok[9];
+    const int y = blockIdx.y;
+    const int col = blockIdx.x * C1_PX + lane - 1;             // input column of this lane (lane 0 / 63: halo)
+    const bool col_ok = col >= 0 && col < W;
+    const int cc = min(max(col, 0), W - 1);
+    int off[3];
+    bool row_ok[3];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int yy = y + t / 3 - 1, xc = xx + t % 3 - 1;
-        ok[t] = yy >= 0 && yy < H && xc >= 0 && xc < W;
-        off[t] = ok[t] ? yy * W + xc : pc;
+    for (int r = 0; r < 3; ++r) {
+        const int yy = y + r - 1;
+        row_ok[r] = yy >= 0 && yy < H;
+        off[r] = min(max(yy, 0), H - 1) * W + cc;
     }
     const int cpw = (Cin + C1_WAVES - 1) / C1_WAVES;
     const int c_lo = wave * cpw, c_hi = min(Cin, c_lo + cpw);
-    float acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    float acc = 0.f;
+#define C1_ONE_CHANNEL(V0, V1, V2, WP)                                                                       \
+    {                                                                                                        \
+        const float v_[3] = {V0, V1, V2};                                                                    \
+        _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                                      \
+            const float m_ = (row_ok[r] && col_ok) ? v_[r] : 0.f;         /* zero padding */                 \
+            const float l_ = __shfl_up(m_, 1), rr_ = __shfl_down(m_, 1);  /* columns col-1, col+1 */         \
+            acc = fmaf((WP)[3 * r], l_, acc);                                                                \
+            acc = fmaf((WP)[3 * r + 1], m_, acc);                                                            \
+            acc = fmaf((WP)[3 * r + 2], rr_, acc);                                                           \
+        }                                                                                                    \
+    }
     int c = c_lo;
     for (; c + 8 <= c_hi; c += 8) {
-        float v[8][9];
+        float v[8][3];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const float* xp = x + ((size_t)b * Cin + c + k) * HW;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) v[k][t] = xp[off[t]];
+            for (int r = 0; r < 3; ++r) v[k][r] = xp[off[r]];
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float* wp = w + (size_t)(c + k) * 9;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) acc[t] = fmaf(wp[t], v[k][t], acc[t]);
-        }
+        for (int k = 0; k < 8; ++k) C1_ONE_CHANNEL(v[k][0], v[k][1], v[k][2], w + (size_t)(c + k) * 9)
     }
     for (; c < c_hi; ++c) {
         const float* xp = x + ((size_t)b * Cin + c) * HW;
-        const float* wp = w + (size_t)c * 9;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) acc[t] = fmaf(wp[t], xp[off[t]], acc[t]);
+        C1_ONE_CHANNEL(xp[off[0]], xp[off[1]], xp[off[2]], w + (size_t)c * 9)
     }
-    float sum = 0.f;                                 // out-of-image taps contribute zero
-#pragma unroll
-    for (int t = 0; t < 9; ++t) sum += ok[t] ? acc[t] : 0.f;
-    part[wave][lane] = sum;
+#undef C1_ONE_CHANNEL
+    part[wave][lane] = acc;
     __syncthreads();
-    if (wave == 0 && p < HW) {
+    if (wave == 0 && lane >= 1 && lane <= C1_PX && col < W) {
         float r = bias ? bias[0] : 0.f;
 #pragma unroll
         for (int k = 0; k < C1_WAVES; ++k) r += part[k][lane];
-        out[(size_t)b * HW + p] = r;
+        out[(size_t)b * HW + (size_t)y * W + col] = r;
     }
 }
 
@@ -1133,7 +1137,8 @@ int tcs_instance_norm(const float* x, int B, int C, int H, int W, float eps, int
 int tcs_conv3x3_cout1(const float* x, const float* w_oihw, const float* bias, int B, int Cin, int H, int W, float* out,
                       tcs_stream_t stream) {
     if (!x || !w_oihw || !out || B <= 0 || B > 65535 || Cin <= 0 || H <= 0 || W <= 0) return TCS_EINVAL;
-    hipLaunchKernelGGL(k_conv3x3_cout1, dim3(tcs_cdiv((long long)H * W, 64), B), dim3(64 * C1_WAVES), 0, tcs_stream(stream), x, w_oihw, bias,
+    if (H > 65535) return TCS_EINVAL;
+    hipLaunchKernelGGL(k_conv3x3_cout1, dim3(tcs_cdiv(W, C1_PX), H, B), dim3(64 * C1_WAVES), 0, tcs_stream(stream), x, w_oihw, bias,
                        Cin, H, W, out);
     return tcs_launch_status();
 }

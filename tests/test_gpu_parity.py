@@ -472,6 +472,20 @@ def test_extractor_block_vs_torch(dev, kind, cin, cout, stride, monkeypatch):
     assert maxdiff(got, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("shape", [(1, 256, 120, 160), (2, 37, 7, 61), (1, 8, 3, 125)])
+def test_conv3x3_cout1_vs_torch(dev, shape):
+    """FlowHead.conv2 (update.py:13): the single-output 3x3 reduction kernel, full size and ragged sizes."""
+    from tcs_mi355 import ops
+    B, Cin, H, W = shape
+    gen = torch.Generator().manual_seed(Cin)
+    x = torch.randn(B, Cin, H, W, generator=gen)
+    w = torch.randn(1, Cin, 3, 3, generator=gen) * 0.1
+    bias = torch.randn(1, generator=gen)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    got = ops.conv3x3_cout1(D(x, dev), D(w, dev), D(bias, dev))
+    assert maxdiff(got, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
 def test_batched_sequences_match_single(dev, model):
     """Independent sequences stacked on the batch dimension (bench.py --seqs-per-gpu) must give what each gives alone:
     every kernel indexes its batch element, per-sample poses / intrinsics / baselines included."""
