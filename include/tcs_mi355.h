@@ -144,6 +144,14 @@ int tcs_grid_halve(const float* grid, int B, int H, int W, float* out, tcs_strea
 /* coords bookkeeping (tc_stereo.py:188-189): coords1 += delta; disp_q = x - coords1 (in place on coords1). */
 int tcs_flow_step(float* coords1, const float* delta, int B, int H, int W, float* disp_q, tcs_stream_t stream);
 
+/* The three stencils that open an iteration's gradient stage, fused: disp_q = x - (coords1 + delta)
+ * (tc_stereo.py:188-189; coords1 itself is left untouched), grad = scale * disp2disp_gradient_xy(disp_q)
+ * (geo_utils.py:115-132, update.py:199), cands = disp2disp_grad_candidates(disp_q, level=2) (geo_utils.py:73-101).
+ * Outputs equal tcs_flow_step + tcs_disp_gradient_xy + tcs_grad_candidates bit for bit.
+ * coords1, delta, disp_q [B,1,H,W]; grad [B,2,H,W]; cands [B,32,H,W]. */
+int tcs_flow_step_grads(const float* coords1, const float* delta, int B, int H, int W, float scale, float* disp_q, float* grad,
+                        float* cands, tcs_stream_t stream);
+
 /* disp2disp_gradient_xy (geo_utils.py:115-132) scaled by `scale` (the 5x of update.py:199):
  * disp [B,1,H,W] -> grad [B,2,H,W]. */
 int tcs_disp_gradient_xy(const float* disp, int B, int H, int W, float scale, float* grad, tcs_stream_t stream);

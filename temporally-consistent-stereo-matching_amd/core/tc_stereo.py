@@ -176,9 +176,10 @@ class TCStereo(nn.Module):
             if a.n_gru_layers >= 2 and a.slow_fast_gru:
                 net_list = self.update_block(net_list, inp_list, iter32=n3, iter16=True, iter08=False, update=False)
             net_list, delta_flow = self.update_block(net_list, inp_list, corr, flows_x, iter32=n3, iter16=a.n_gru_layers >= 2)
-            disp_q = ops.flow_step(coords1, delta_flow)                        # coords1 += delta; disp_q = x - coords1
-            g5 = ops.disp_gradient_xy(disp_q, scale=5.0)                       # 5 * disp2disp_gradient_xy (update.py:199)
-            disp_grad, context = self.disp_grad_refine(None, disp_q, grad_list, g5=g5)
+            # disp_q = x - (coords1 + delta), 5 * disp2disp_gradient_xy (update.py:199) and the gradient candidates in one
+            # launch; coords1 is replaced by the blend kernel's output below
+            disp_q, g5, cands = ops.flow_step_grads(coords1, delta_flow, scale=5.0)
+            disp_grad, context = self.disp_grad_refine(None, disp_q, grad_list, g5=g5, cands=cands)
             last = itr == iters - 1
             fused = {}
             refined, up_mask = self.disp_refine(disp_grad, disp_q, net_list[0], context, test_mode=not last, fused_outputs=fused)

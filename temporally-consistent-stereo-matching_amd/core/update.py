@@ -282,12 +282,13 @@ class DispGradPredictor(nn.Module):
             y = F.interpolate(y, size=rem.shape[-2:], mode="nearest")
         return hip_conv(block.conv2.conv, [(y + rem)], act="leaky")
 
-    def forward(self, disp_grad, disp, clist, g5=None):
+    def forward(self, disp_grad, disp, clist, g5=None, cands=None):
         """`g5`, when given, is 5*disp_grad already produced by the gradient kernel (saves an elementwise launch)."""
         disp = disp.float().contiguous()
         if g5 is None:
             g5 = (5 * disp_grad).contiguous()                    # update.py:199
-        cands = ops.grad_candidates(disp)                        # [N,32,H,W] (update.py:202-204)
+        if cands is None:
+            cands = ops.grad_candidates(disp)                    # [N,32,H,W] (update.py:202-204)
         x4_grad, x4_cand = fork_join([lambda: hip_seq(self.conv_grad_stem, [g5]),
                                       lambda: hip_seq(self.conv_grad_candidate_stem, [cands])], site="stems")
         x4 = hip_seq(self.conv_4_4, [x4_grad, x4_cand, clist[0]])

@@ -65,6 +65,59 @@ __global__ __launch_bounds__(256) void k_grad_candidates(const float* __restrict
     }
 }
 
+// k_flow_step + k_grad_xy + k_grad_candidates in one launch: the three run back to back on the same 19,200-pixel field once
+// per iteration and each is a 4.6-us dispatch.  A neighbour's disparity is recomputed from coords1 + delta (same
+// arithmetic as k_flow_step, so the three outputs are bit-identical to the separate kernels'); coords1 is NOT updated —
+// the caller replaces it with the blend kernel's output (tc_stereo.py:188-189, 212-213).
+__global__ __launch_bounds__(256) void k_flow_step_grads(const float* __restrict__ coords1, const float* __restrict__ delta, int H, int W,
+                                                         float scale, float* __restrict__ disp_q, float* __restrict__ grad,
+                                                         float* __restrict__ cands) {
+    const int b = blockIdx.y, HW = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const int y = p / W, x = p - y * W;
+    const float* c1 = coords1 + (size_t)b * HW;
+    const float* dl = delta + (size_t)b * HW;
+#define DISP_AT(YY, XX) ((float)(XX) - (c1[(YY) * W + (XX)] + dl[(YY) * W + (XX)]))
+    const float c = DISP_AT(y, x);
+    disp_q[(size_t)b * HW + p] = c;
+    {
+        const int xr = min(x + 1, W - 1), yd = min(y + 1, H - 1);
+        const float r = DISP_AT(y, xr), dn = DISP_AT(yd, x);
+        grad[((size_t)b * 2 + 0) * HW + p] = scale * (r - c);
+        grad[((size_t)b * 2 + 1) * HW + p] = scale * (dn - c);
+    }
+    const int dv[8] = {-1, -1, -1, 0, 1, 1, 1, 0};
+    const int du[8] = {-1, 0, 1, 1, 1, 0, -1, -1};
+    float vx[16], vy[16], vz[16];
+#pragma unroll
+    for (int s = 1; s <= 2; ++s) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int yy = y + s * dv[k], xx = x + s * du[k];
+            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
+            const float nb_raw = DISP_AT(yc, xc);
+            const float nb = ok ? nb_raw : 0.f;
+            const int i = (s - 1) * 8 + k;
+            vx[i] = (float)(s * du[k]);
+            vy[i] = (float)(s * dv[k]);
+            vz[i] = nb - c;
+        }
+    }
+#undef DISP_AT
+    float* o = cands + (size_t)b * 32 * HW + p;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int r = (k + 2) & 15;
+        const float nx = vy[k] * vz[r] - vz[k] * vy[r];
+        const float ny = vz[k] * vx[r] - vx[k] * vz[r];
+        const float nz = vx[k] * vy[r] - vy[k] * vx[r];
+        o[(size_t)k * HW] = -nx / nz;
+        o[(size_t)(16 + k) * HW] = -ny / nz;
+    }
+}
+
 // update.py:259-289
 __global__ __launch_bounds__(256) void k_propagate(const float* __restrict__ grad, const float* __restrict__ disp, int H, int W,
                                                    float* __restrict__ out) {
@@ -175,6 +228,14 @@ int tcs_flow_step(float* coords1, const float* delta, int B, int H, int W, float
     if (!coords1 || !delta || !disp_q || B <= 0 || H <= 0 || W <= 0) return TCS_EINVAL;
     const int n = B * H * W;
     hipLaunchKernelGGL(k_flow_step, dim3(tcs_cdiv(n, 256)), dim3(256), 0, tcs_stream(stream), coords1, delta, W, n, disp_q);
+    return tcs_launch_status();
+}
+
+int tcs_flow_step_grads(const float* coords1, const float* delta, int B, int H, int W, float scale, float* disp_q, float* grad,
+                        float* cands, tcs_stream_t stream) {
+    if (!coords1 || !delta || !disp_q || !grad || !cands || B <= 0 || B > 65535 || H <= 0 || W <= 0) return TCS_EINVAL;
+    hipLaunchKernelGGL(k_flow_step_grads, dim3(tcs_cdiv((long long)H * W, 256), B), dim3(256), 0, tcs_stream(stream), coords1, delta, H, W,
+                       scale, disp_q, grad, cands);
     return tcs_launch_status();
 }
 

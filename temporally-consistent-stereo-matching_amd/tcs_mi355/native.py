@@ -59,6 +59,7 @@ SIGNATURES = {
     "tcs_bilinear_sample": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp]),
     "tcs_grid_halve": (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_fp]),
     "tcs_flow_step": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp]),
+    "tcs_flow_step_grads": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_f, c_fp, c_fp, c_fp, c_fp]),
     "tcs_disp_gradient_xy": (c_int, [c_fp, c_int, c_int, c_int, c_f, c_fp, c_fp]),
     "tcs_grad_candidates": (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_fp]),
     "tcs_propagate_disparity": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp]),

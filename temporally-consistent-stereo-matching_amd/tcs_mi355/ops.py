@@ -224,6 +224,17 @@ def flow_step(coords1, delta, disp_q=None):
     return disp_q
 
 
+def flow_step_grads(coords1, delta, scale: float = 1.0):
+    """(disp_q, scale * gradient_xy(disp_q), grad_candidates(disp_q)) with disp_q = x - (coords1 + delta), one launch."""
+    B, _, H, W = _dims4(coords1, "coords1")
+    if tuple(delta.shape) != (B, 1, H, W):
+        raise ValueError("flow_step_grads: bad delta shape")
+    disp_q, grad, cands = torch.empty_like(coords1), _new(coords1, B, 2, H, W), _new(coords1, B, 32, H, W)
+    nv.check(nv.lib().tcs_flow_step_grads(nv.ptr(coords1, "coords1"), nv.ptr(delta, "delta"), B, H, W, float(scale), nv.ptr(disp_q),
+                                          nv.ptr(grad), nv.ptr(cands), nv.stream()), "tcs_flow_step_grads")
+    return disp_q, grad, cands
+
+
 def disp_gradient_xy(disp, scale: float = 1.0, out=None):
     B, _, H, W = _dims4(disp, "disp")
     out = _new(disp, B, 2, H, W) if out is None else out

@@ -472,6 +472,25 @@ def test_extractor_block_vs_torch(dev, kind, cin, cout, stride, monkeypatch):
     assert maxdiff(got, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
+def test_flow_step_grads_equals_separate_kernels(dev):
+    """The fused opening of the gradient stage must equal tcs_flow_step + tcs_disp_gradient_xy + tcs_grad_candidates
+    bit for bit (same arithmetic per pixel), also on ragged sizes and batch 2."""
+    from tcs_mi355 import ops
+    for B, H, W in ((1, 120, 160), (2, 7, 13)):
+        gen = torch.Generator().manual_seed(H)
+        xs = torch.arange(W, dtype=torch.float32).view(1, 1, 1, W).expand(B, 1, H, W)
+        coords1 = (xs - torch.rand(B, 1, H, W, generator=gen) * 30).contiguous().to(dev)
+        delta = torch.randn(B, 1, H, W, generator=gen).to(dev)
+        dq, g5, cands = ops.flow_step_grads(coords1, delta, scale=5.0)
+        c_sep = coords1.clone()
+        dq_sep = ops.flow_step(c_sep, delta)
+        assert torch.equal(dq, dq_sep)
+        assert torch.equal(g5, ops.disp_gradient_xy(dq_sep, scale=5.0))
+        sep_c = ops.grad_candidates(dq_sep)
+        both_nan = torch.isnan(cands) & torch.isnan(sep_c)           # 0/0 where three neighbours are collinear
+        assert torch.equal(torch.where(both_nan, torch.zeros_like(cands), cands), torch.where(both_nan, torch.zeros_like(sep_c), sep_c))
+
+
 @pytest.mark.parametrize("shape", [(1, 256, 120, 160), (2, 37, 7, 61), (1, 8, 3, 125)])
 def test_conv3x3_cout1_vs_torch(dev, shape):
     """FlowHead.conv2 (update.py:13): the single-output 3x3 reduction kernel, full size and ragged sizes."""
