@@ -210,8 +210,11 @@ def main():
     roof = lookup_roofline(probe, snaps)
     ops.LOOKUP_PROBE = None
 
-    elapsed = tdist.max_over_ranks(elapsed)
-    total_pairs = a.steps * S * max(world, 1)
+    # the run's only collective (besides the two barriers): per-rank [pairs, elapsed]; the MAX over ranks of the elapsed
+    # time and the aggregate come from it (EPE statistics ride the same vector in evaluation runs)
+    vecs = tdist.gather_vectors(np.array([a.steps * S, elapsed], np.float64))
+    elapsed = max(float(v[1]) for v in vecs)
+    total_pairs = sum(int(v[0]) for v in vecs)
     value = total_pairs / elapsed
 
     # accuracy of the synthetic run (random-init weights: parity, not quality, is what is checked)
@@ -257,8 +260,6 @@ def main():
                    "lookup": {k: roof_b[k] for k in ("achieved", "frac", "avg_launch_us", "algorithmic_bytes_per_launch")} if roof_b else None}
         del runner_b
 
-    # the run's only collective: per-rank [frames, elapsed] (EPE statistics ride the same vector in eval runs)
-    vecs = tdist.gather_vectors(np.array([a.steps * S, elapsed], np.float64))
 
     if rank == 0:
         line = {
