@@ -176,6 +176,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     native.lib()
+    if os.environ.get("TCS_MI355_DIST_BACKEND") == "gloo":        # rehearsal: several ranks may share a GPU
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

@@ -25,7 +25,8 @@ def init_from_env(force_backend: str | None = None) -> Tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        backend = force_backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        # TCS_MI355_DIST_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks
+        backend = force_backend or os.environ.get("TCS_MI355_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
