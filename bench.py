@@ -108,7 +108,10 @@ def lookup_burst_us(dev, B, n=200, reps=5):
     f1, f2 = torch.randn(B, 256, h, w, generator=gen).to(dev), torch.randn(B, 256, h, w, generator=gen).to(dev)
     pyr = ops.corr_build(f1, f2)
     xs = torch.arange(w, dtype=torch.float32).view(1, 1, 1, w).expand(B, 1, h, w)
-    coords = (xs - torch.rand(B, 1, h, w, generator=gen) * 40.0).contiguous().to(dev)
+    # a smooth disparity field (ramp + gentle waves), like the fields the refinement loop produces
+    yy = torch.arange(h, dtype=torch.float32).view(1, 1, h, 1)
+    disp = 4.0 + 30.0 * yy / h + 2.0 * torch.sin(xs / 17.0) * torch.cos(yy / 11.0)
+    coords = (xs - disp).contiguous().to(dev)
     out = ops.corr_lookup(pyr, coords, 4)
     torch.cuda.synchronize()
     g, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()

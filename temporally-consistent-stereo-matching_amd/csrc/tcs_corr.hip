@@ -223,9 +223,13 @@ __global__ __launch_bounds__(64 * LPB) void k_corr_lookup(const float* __restric
     struct { const float* coords; float* out; unsigned long long* stamps; int B, H, W, radius; } a =
         {coords_p, out_p, stamps_p, Bn, Hn, Wn, radius_n};
     const int lane = threadIdx.x & 63;
-    // LPB pyramid levels per workgroup (one wave each); the 4 / LPB workgroups of a 64-pixel group are neighbours in the grid
-    const unsigned grp = blockIdx.x / (4 / LPB);
-    const int level = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % (4 / LPB)) * LPB + (int)(threadIdx.x >> 6));
+    // LPB pyramid levels per workgroup (one wave each).  Workgroup index = level_block * G8 + pixel_group with G8 a multiple
+    // of 8: consecutive workgroup ids go round-robin over the 8 XCDs, so all levels of a pixel group — and the same groups
+    // in every iteration — stay on one XCD's L2 (per XCD 1/8 of the 23 MB pyramid, which fits its 4 MB; with the levels of
+    // a group spread over XCDs the PMC read traffic doubled).
+    const unsigned G8 = gridDim.x / (4 / LPB);
+    const unsigned grp = blockIdx.x % G8;
+    const int level = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / G8) * LPB + (int)(threadIdx.x >> 6));
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();      // first instruction; stored at the end
     const int HW = a.H * a.W;
     const unsigned total = (unsigned)a.B * (unsigned)HW;                      // host checks B*H*W < 2^31
@@ -364,7 +368,8 @@ static int lookup_levels_per_block(long long groups) {
 int tcs_corr_lookup_blocks(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     const long long groups = tcs_cdiv((long long)B * H * W, 64);
-    return (int)(groups * (4 / lookup_levels_per_block(groups)));
+    const long long g8 = (groups + 7) / 8 * 8;
+    return (int)(g8 * (4 / lookup_levels_per_block(groups)));
 }
 
 int tcs_corr_lookup(const float* pyr0, const float* pyr1, const float* pyr2, const float* pyr3,
@@ -378,17 +383,18 @@ int tcs_corr_lookup(const float* pyr0, const float* pyr1, const float* pyr2, con
     a.coords = coords; a.out = out; a.stamps = stamps; a.B = B; a.H = H; a.W = W; a.radius = radius;
     const int blocks = tcs_cdiv((long long)B * H * W, 64);
     const int lpb = lookup_levels_per_block(blocks);
+    const int g8 = (blocks + 7) / 8 * 8;
     if (radius == 4 && lpb == 2)
-        hipLaunchKernelGGL((k_corr_lookup<4, 2>), dim3(blocks * 2), dim3(128), 0, tcs_stream(stream), pyr0, pyr1, pyr2, pyr3, coords, out, B,
+        hipLaunchKernelGGL((k_corr_lookup<4, 2>), dim3(g8 * 2), dim3(128), 0, tcs_stream(stream), pyr0, pyr1, pyr2, pyr3, coords, out, B,
                            H, W, radius, stamps);
     else if (radius == 4 && lpb == 1)
-        hipLaunchKernelGGL((k_corr_lookup<4, 1>), dim3(blocks * 4), dim3(64), 0, tcs_stream(stream), pyr0, pyr1, pyr2, pyr3, coords, out, B,
+        hipLaunchKernelGGL((k_corr_lookup<4, 1>), dim3(g8 * 4), dim3(64), 0, tcs_stream(stream), pyr0, pyr1, pyr2, pyr3, coords, out, B,
                            H, W, radius, stamps);
     else if (radius == 4)
-        hipLaunchKernelGGL(k_corr_lookup<4>, dim3(blocks), dim3(256), 0, tcs_stream(stream), pyr0, pyr1, pyr2, pyr3, coords, out, B, H, W,
+        hipLaunchKernelGGL(k_corr_lookup<4>, dim3(g8), dim3(256), 0, tcs_stream(stream), pyr0, pyr1, pyr2, pyr3, coords, out, B, H, W,
                            radius, stamps);
     else
-        hipLaunchKernelGGL(k_corr_lookup<0>, dim3(blocks), dim3(256), 0, tcs_stream(stream), pyr0, pyr1, pyr2, pyr3, coords, out, B, H, W,
+        hipLaunchKernelGGL(k_corr_lookup<0>, dim3(g8), dim3(256), 0, tcs_stream(stream), pyr0, pyr1, pyr2, pyr3, coords, out, B, H, W,
                            radius, stamps);
     return tcs_launch_status();
 }
