@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Free-running (not teacher-forced) 2-frame comparison: eager HIP, graph HIP, oracle."""
+"""(Uses the CPU oracle, hence kept under tests/.)  Free-running (not teacher-forced) 2-frame comparison: eager HIP, graph HIP, oracle."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import tcs_paths; tcs_paths.add_product_path()
 import torch

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""GPU-side debugging aid: stage-by-stage HIP vs oracle differences on frames 0 and 1 of the bench clip."""
+"""(Uses the CPU oracle, hence kept under tests/.)  GPU-side debugging aid: stage-by-stage HIP vs oracle differences on frames 0 and 1 of the bench clip."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import tcs_paths; tcs_paths.add_product_path()
 import numpy as np, torch
