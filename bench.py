@@ -97,6 +97,11 @@ class ClipRunner:
         return out
 
 
+def _quarter(n):
+    """1/4-resolution size of a frame dimension after InputPadder(divis_by=32)."""
+    return (n + 31) // 32 * 32 // 4
+
+
 def lookup_burst_us(dev, B, n=200, reps=5):
     """Average duration of one corr-lookup launch measured with HIP events on the launch stream: `n` back-to-back launches
     of the production kernel (same grid: B x 120 x 160 pixels, radius 4, 4 levels) are captured into a HIP graph like the
@@ -104,7 +109,7 @@ def lookup_burst_us(dev, B, n=200, reps=5):
     A single launch cannot be bracketed: an event pair costs ~5 us on this stack, more than the kernel."""
     from tcs_mi355 import ops
     gen = torch.Generator().manual_seed(77)
-    h, w = HEIGHT // 4, WIDTH // 4
+    h, w = _quarter(HEIGHT), _quarter(WIDTH)
     f1, f2 = torch.randn(B, 256, h, w, generator=gen).to(dev), torch.randn(B, 256, h, w, generator=gen).to(dev)
     pyr = ops.corr_build(f1, f2)
     xs = torch.arange(w, dtype=torch.float32).view(1, 1, 1, w).expand(B, 1, h, w)
@@ -199,10 +204,15 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch kernels eagerly instead of replaying HIP graphs")
     ap.add_argument("--seqs-per-gpu", type=int, default=1,
                     help="independent sequences stacked on the batch dimension of every launch (default 1 = BASELINE configs[1])")
+    ap.add_argument("--size", default=None, metavar="HxW",
+                    help="frame size other than BASELINE configs[1]'s 480x640, e.g. 375x1242 for configs[4] (KITTI raw latency)")
     ap.add_argument("--batched-leg", type=int, default=4,
                     help="after the timed run, also time this many sequences per launch (reported under batched_leg; 0/1 = skip)")
     a = ap.parse_args()
 
+    global HEIGHT, WIDTH
+    if a.size:
+        HEIGHT, WIDTH = (int(v) for v in a.size.lower().split("x"))
     from tcs_mi355 import dist as tdist
     from tcs_mi355 import native, synth
     rank, world, local = tdist.init_from_env()
@@ -247,7 +257,7 @@ def main():
     ops.LOOKUP_PROBE = None
     with torch.no_grad():
         try:
-            roof = lookup_roofline(probe, snaps, lookup_burst_us(dev, S), S * (HEIGHT // 4) * (WIDTH // 4))
+            roof = lookup_roofline(probe, snaps, lookup_burst_us(dev, S), S * _quarter(HEIGHT) * _quarter(WIDTH))
         except Exception as e:                    # never lose the headline line over the auxiliary timing
             log(f"lookup roofline timing failed: {type(e).__name__}: {e}")
             roof = None
@@ -302,7 +312,7 @@ def main():
               tb = time.perf_counter() - tb
           ops.LOOKUP_PROBE = None
           with torch.no_grad():
-              roof_b = lookup_roofline(probe_b, snaps_b, lookup_burst_us(dev, Sb), Sb * (HEIGHT // 4) * (WIDTH // 4))
+              roof_b = lookup_roofline(probe_b, snaps_b, lookup_burst_us(dev, Sb), Sb * _quarter(HEIGHT) * _quarter(WIDTH))
           batched = {"seqs_per_gpu": Sb, "value": round(a.steps * Sb / tb, 4), "unit": "stereo-pairs/s",
                      "ms_per_step": round(1e3 * tb / a.steps, 3),
                      "lookup": {k: roof_b[k] for k in ("achieved", "frac", "avg_launch_us", "algorithmic_bytes_per_launch", "in_kernel")}}
@@ -315,11 +325,12 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "stereo-pairs/sec at 640x480 D=192, 32 GRU iters", "value": round(value, 4), "unit": "stereo-pairs/s",
+            "metric": f"stereo-pairs/sec at {WIDTH}x{HEIGHT} D=192, 32 GRU iters", "value": round(value, 4), "unit": "stereo-pairs/s",
             "n_gpus": max(world, 1), "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "contraction": CONTRACTION,
-            "config": {"workload": "BASELINE configs[1]: 640x480 synthetic sequence len=10, D=192, 32 iters, "
+            "config": {"workload": ("BASELINE configs[1]: 640x480" if (HEIGHT, WIDTH) == (480, 640) else f"{WIDTH}x{HEIGHT}")
+                                   + " synthetic sequence len=10, D=192, 32 iters, "
                                    + ("one sequence per GPU" if S == 1 else f"{S} independent sequences batched per GPU"),
                        "frames_per_rank": a.steps * S, "seqs_per_gpu": S, "weights": "key-seeded synthetic (tcs_mi355.weights)",
                        "launch": "eager" if a.eager else "hip-graph replay"},
