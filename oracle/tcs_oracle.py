@@ -386,13 +386,20 @@ def _interp(x, like):
     return F.interpolate(x, like.shape[2:], mode="bilinear", align_corners=True)   # update.py:122-124
 
 
-def update_block(W, net, inp, corr, flow, name="update_block"):
-    """a13/a14 (update.py:145-168) for n_gru_layers=3: gru32 -> gru16 -> encoder -> gru08 -> flow head."""
+def update_block(W, net, inp, corr=None, flow=None, name="update_block", iter08=True, iter16=True, iter32=True, update=True):
+    """a13/a14 (update.py:145-168) for n_gru_layers=3 (the only depth the model's gradient U-Net accepts, update.py:206-210):
+    gru32 -> gru16 -> encoder -> gru08 -> flow head; the iter* / update switches serve the slow-fast schedule
+    (tc_stereo.py:182-187)."""
     net = list(net)
-    net[2] = conv_gru(W, name + ".gru32", net[2], *inp[2], _pool2x(net[1]))
-    net[1] = conv_gru(W, name + ".gru16", net[1], *inp[1], _pool2x(net[0]), _interp(net[2], net[1]))
-    mf = motion_encoder(W, flow, corr, name + ".encoder")
-    net[0] = conv_gru(W, name + ".gru08", net[0], *inp[0], mf, _interp(net[1], net[0]))
+    if iter32:
+        net[2] = conv_gru(W, name + ".gru32", net[2], *inp[2], _pool2x(net[1]))
+    if iter16:
+        net[1] = conv_gru(W, name + ".gru16", net[1], *inp[1], _pool2x(net[0]), _interp(net[2], net[1]))
+    if iter08:
+        mf = motion_encoder(W, flow, corr, name + ".encoder")
+        net[0] = conv_gru(W, name + ".gru08", net[0], *inp[0], mf, _interp(net[1], net[0]))
+    if not update:
+        return net
     d = F.relu(_conv(W, name + ".flow_head.conv1", net[0]))
     return net, _conv(W, name + ".flow_head.conv2", d)
 
@@ -592,6 +599,9 @@ def tc_stereo_forward(W, image1, image2, iters=12, params=None, args=None, trace
     for itr in range(iters):
         corr = corr_lookup(pyr, coords1, args.corr_radius)
         flow_x = coords1 - coords0
+        if args.slow_fast_gru:                                     # tc_stereo.py:182-185: extra coarse-level sweeps
+            net = update_block(W, net, inp, iter32=True, iter16=False, iter08=False, update=False)
+            net = update_block(W, net, inp, iter32=True, iter16=True, iter08=False, update=False)
         net, delta = update_block(W, net, inp, corr, flow_x)
         coords1 = coords1 + delta
         disp_q = coords0 - coords1

@@ -368,6 +368,54 @@ def test_e2e_kitti_shape_vs_oracle(dev, oracle, synth_weights, model):
         assert epe(got[t], want[t]) <= 1e-4, t
 
 
+@pytest.mark.parametrize("name,over", [("separate_fnet", dict(shared_backbone=False)),
+                                        ("context_norm_batch", dict(context_norm="batch")),
+                                        ("shared_backbone", dict(slow_fast_gru=True))])
+def test_other_configurations_vs_oracle(dev, oracle, key_shapes, name, over):
+    """The architecture switches of TCStereo(args) (tc_stereo.py:29-58) other than the shipped evaluation setting:
+    separate feature network (instance norm at full resolution), batch-norm context network (stays on PyTorch-ROCm),
+    slow-fast GRU schedule.  First frame + one temporal frame, 3 iterations, against the CPU oracle (whose slow-fast path
+    is pinned by tests/golden/e2e_configs.npz).  n_gru_layers < 3 is not a usable switch of this model
+    (update.py:206-210 indexes three context levels)."""
+    from argparse import Namespace
+    from core.tc_stereo import TCStereo
+    from tcs_mi355 import synth
+    from tcs_mi355.harness import run_sequence
+    from tcs_mi355.weights import synth_state_dict
+    W = synth_state_dict(key_shapes[name])
+    base = dict(hidden_dims=[128] * 3, shared_backbone=True, corr_levels=4, corr_radius=4, n_downsample=2, context_norm="none",
+                slow_fast_gru=False, n_gru_layers=3, mixed_precision=False, init_thres=0.5)
+    base.update(over)
+    m = TCStereo(Namespace(**base))
+    m.load_state_dict(W, strict=True)
+    m = m.to(dev).eval()
+    seq = synth.make_sequence(17, n_frames=2, height=96, width=128, max_disp=32.0)
+    got, want = [], []
+    run_sequence(m, seq, iters=3, device=dev, collect=got)
+    run_sequence(lambda a, b, **kw: oracle.tc_stereo_forward(W, a, b, iters=kw["iters"], params=kw["params"], args=oracle.default_args(**over)),
+                 seq, iters=3, device=torch.device("cpu"), collect=want)
+    for t in range(2):
+        assert epe(got[t], want[t]) <= 1e-4, (over, t)
+
+
+def test_slow_fast_schedule_golden(dev, synth_weights):
+    """HIP against the reference's own slow-fast output (tests/golden/e2e_configs.npz)."""
+    import os
+    from argparse import Namespace
+    from conftest import GOLDEN
+    from core.tc_stereo import TCStereo
+    from tcs_mi355 import synth
+    g = np.load(os.path.join(GOLDEN, "e2e_configs.npz"))
+    m = TCStereo(Namespace(hidden_dims=[128] * 3, shared_backbone=True, corr_levels=4, corr_radius=4, n_downsample=2, context_norm="none",
+                           slow_fast_gru=True, n_gru_layers=3, mixed_precision=False, init_thres=0.5))
+    m.load_state_dict(synth_weights, strict=True)
+    m = m.to(dev).eval()
+    fr = synth.make_sequence(23, n_frames=1, height=96, width=128, max_disp=32.0).frames[0]
+    out = m(D(fr.image1, dev)[None], D(fr.image2, dev)[None], iters=4, test_mode=True)
+    assert epe(out["flow"], g["slow_fast_flow"]) <= 1e-4
+    assert epe(out["flow_q"], g["slow_fast_flow_q"]) <= 1e-4
+
+
 def test_no_cpu_fallback(dev, model):
     with pytest.raises(RuntimeError):
         model(torch.zeros(1, 3, 64, 64), torch.zeros(1, 3, 64, 64), iters=1, test_mode=True)

@@ -173,3 +173,18 @@ def test_e2e_temporal_clip(oracle, e2e_golden, synth_weights):
         tag = "clip" if t == 0 else "rp_clip"
         assert epe(out["flow"], e2e_golden[f"{tag}_flow_{t}"]) <= 1e-4, t
         assert epe(out["flow_q"], e2e_golden[f"{tag}_flow_q_{t}"]) <= 1e-4, t
+
+
+def test_slow_fast_schedule_golden(oracle, synth_weights):
+    """The slow-fast GRU schedule (tc_stereo.py:182-187) against the reference's own output
+    (tests/golden/e2e_configs.npz, tools/make_goldens_configs.py)."""
+    import os
+    import numpy as np
+    import torch
+    from conftest import GOLDEN, T, epe
+    from tcs_mi355 import synth
+    g = np.load(os.path.join(GOLDEN, "e2e_configs.npz"))
+    fr = synth.make_sequence(23, n_frames=1, height=96, width=128, max_disp=32.0).frames[0]
+    out = oracle.tc_stereo_forward(synth_weights, T(fr.image1)[None], T(fr.image2)[None], iters=4, args=oracle.default_args(slow_fast_gru=True))
+    assert epe(out["flow"], g["slow_fast_flow"]) <= 1e-4
+    assert epe(out["flow_q"], g["slow_fast_flow_q"]) <= 1e-4
