@@ -167,9 +167,13 @@ int tcs_propagate_disparity(const float* grad, const float* disp, int B, int H, 
 
 /* update.py:298-300 + tc_stereo.py:198-202: softmax over the 9 logits (max-subtracted), blend the 9
  * candidates (first 9 channels of a [B,cand_ctot,H,W] buffer), and emit
- *   refined [B,1,H,W], delta_disp = refined - disp_q [B,1,H,W] (nullable), coords1 = x - refined (nullable). */
+ *   refined [B,1,H,W], delta_disp = refined - disp_q [B,1,H,W] (nullable), coords1 = x - refined (nullable),
+ *   and the next iteration's motion-encoder input coords1 - x (tc_stereo.py:180) twice (both nullable): flow_x [B,1,H,W]
+ *   and flow_x_ch, one channel plane per batch element at a stride of flow_x_ch_bstride floats (channel 127 of the
+ *   [B,128,H,W] motion feature buffer, update.py:126). */
 int tcs_softmax_blend(const float* logits9, const float* cand, int cand_ctot, const float* disp_q,
-                      int B, int H, int W, float* refined, float* delta_disp, float* coords1, tcs_stream_t stream);
+                      int B, int H, int W, float* refined, float* delta_disp, float* coords1, float* flow_x, float* flow_x_ch,
+                      long long flow_x_ch_bstride, tcs_stream_t stream);
 
 /* TCStereo.upsample_flow (tc_stereo.py:75-88) with factor 4, applied to flow = -disp:
  * disp [B,1,H,W], mask [B,144,H,W] -> flow_up [B,1,4H,4W]; flow_q [B,1,H,W] = -disp (nullable).

@@ -168,23 +168,28 @@ class TCStereo(nn.Module):
 
         n3 = a.n_gru_layers == 3
         refined = up_mask = None
+        # coords1 - coords0, the motion encoder's flow input (tc_stereo.py:180): once here, afterwards the blend kernel writes
+        # it for the next iteration — as a tensor for the 7x7 stem and into channel 127 of the motion feature buffer
+        flows_x = coords1 - coords0
+        motion_buf = torch.empty(coords1.shape[0], 128, coords1.shape[2], coords1.shape[3], dtype=torch.float32, device=coords1.device)
+        motion_buf[:, 127:128].copy_(flows_x)
         for itr in range(iters):
             corr = corr_fn(coords1)
-            flows_x = coords1 - coords0
             if n3 and a.slow_fast_gru:
                 net_list = self.update_block(net_list, inp_list, iter32=True, iter16=False, iter08=False, update=False)
             if a.n_gru_layers >= 2 and a.slow_fast_gru:
                 net_list = self.update_block(net_list, inp_list, iter32=n3, iter16=True, iter08=False, update=False)
-            net_list, delta_flow = self.update_block(net_list, inp_list, corr, flows_x, iter32=n3, iter16=a.n_gru_layers >= 2)
+            net_list, delta_flow = self.update_block(net_list, inp_list, corr, flows_x, iter32=n3, iter16=a.n_gru_layers >= 2,
+                                                     motion_out=motion_buf)
             # disp_q = x - (coords1 + delta), 5 * disp2disp_gradient_xy (update.py:199) and the gradient candidates in one
             # launch; coords1 is replaced by the blend kernel's output below
             disp_q, g5, cands = ops.flow_step_grads(coords1, delta_flow, scale=5.0)
             disp_grad, context = self.disp_grad_refine(None, disp_q, grad_list, g5=g5, cands=cands)
             last = itr == iters - 1
-            fused = {}
+            fused = {"flow_x_channel": motion_buf[:, 127:128]}
             refined, up_mask = self.disp_refine(disp_grad, disp_q, net_list[0], context, test_mode=not last, fused_outputs=fused)
             net_list = [self.hiddenstate_update(net_list[0], fused["delta_disp"]), net_list[1], net_list[2]]
-            coords1 = fused["coords1"]
+            coords1, flows_x = fused["coords1"], fused["flow_x"]
             if trace is not None:
                 trace["iters"].append(dict(corr=corr, delta=delta_flow, disp_q=disp_q, refined=refined,
                                            net=[t.clone() for t in net_list]))

@@ -185,15 +185,20 @@ class BasicMotionEncoder(nn.Module):
         self.convf2 = _conv(64, 64, 3)
         self.conv = _conv(128, 127, 3)
 
-    def forward(self, flow, corr):
+    def forward(self, flow, corr, out=None):
+        """`out`, when given, is a [N,128,H,W] buffer whose channel 127 ALREADY holds `flow` (the blend kernel of the
+        previous iteration writes it there): only channels 0..126 are produced here."""
         flow = flow.float().contiguous()
         cor, flo = fork_join([
             lambda: hip_conv(self.convc2, [hip_conv(self.convc1, [corr], act="relu")], act="relu"),
             lambda: hip_conv(self.convf2, [hip_conv(self.convf1, [flow], act="relu")], act="relu")], site="enc")
         n, _, h, w = flow.shape
-        out = torch.empty(n, 128, h, w, dtype=torch.float32, device=flow.device)
+        prefilled = out is not None
+        if not prefilled:
+            out = torch.empty(n, 128, h, w, dtype=torch.float32, device=flow.device)
         hip_conv(self.conv, [cor, flo], act="relu", out=out)     # channels 0..126 in place: no torch.cat
-        out[:, 127:128].copy_(flow)
+        if not prefilled:
+            out[:, 127:128].copy_(flow)
         return out
 
 
@@ -225,8 +230,9 @@ class BasicMultiUpdateBlock(nn.Module):
                 if m.bias is not None:
                     nn.init.constant_(m.bias, 0)
 
-    def forward(self, net, inp, corr=None, flow=None, iter08=True, iter16=True, iter32=True, update=True):
-        """Coarse-to-fine GRU sweep (update.py:145-168); `net` is updated in place like the reference."""
+    def forward(self, net, inp, corr=None, flow=None, iter08=True, iter16=True, iter32=True, update=True, motion_out=None):
+        """Coarse-to-fine GRU sweep (update.py:145-168); `net` is updated in place like the reference.
+        `motion_out`: see BasicMotionEncoder.forward(out=...)."""
         n = self.args.n_gru_layers
 
         def coarse():            # gru32 -> gru16: independent of the motion encoder (which only feeds gru08)
@@ -240,7 +246,7 @@ class BasicMultiUpdateBlock(nn.Module):
         if iter08:
             # the encoder (which forks again) stays on the current stream: ROCm 7.2 segfaults in hipStreamEndCapture when
             # a side branch of a captured fork forks a second time
-            motion, up16 = fork_join([lambda: self.encoder(flow, corr), coarse], site="coarse")
+            motion, up16 = fork_join([lambda: self.encoder(flow, corr, out=motion_out), coarse], site="coarse")
             extra = (up16,) if n > 1 else ()
             net[0] = self.gru08(net[0], *inp[0], motion, *extra)
         else:
@@ -340,8 +346,10 @@ class DispRefine(nn.Module):
         logits = hip_seq(self.w_head, [fused])
         if fused_outputs is not None:
             coords1 = torch.empty_like(disp)
-            refined, delta = ops.softmax_blend(logits, feats27, disp_q=disp, want_delta=True, coords1=coords1)
-            fused_outputs.update(delta_disp=delta, coords1=coords1)
+            flow_x = torch.empty_like(disp)
+            refined, delta = ops.softmax_blend(logits, feats27, disp_q=disp, want_delta=True, coords1=coords1, flow_x=flow_x,
+                                               flow_x_channel=fused_outputs.get("flow_x_channel"))
+            fused_outputs.update(delta_disp=delta, coords1=coords1, flow_x=flow_x)
         else:
             refined, _ = ops.softmax_blend(logits, feats27)
         mask = None

@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256) void k_propagate(const float* __restrict__ gra
 // update.py:298-300 and tc_stereo.py:198-202
 __global__ __launch_bounds__(256) void k_softmax_blend(const float* __restrict__ logits, const float* __restrict__ cand, int cand_ctot,
                                                        const float* __restrict__ disp_q, int W, int HW, float* __restrict__ refined,
-                                                       float* __restrict__ delta, float* __restrict__ coords1) {
+                                                       float* __restrict__ delta, float* __restrict__ coords1,
+                                                       float* __restrict__ flow_x, float* __restrict__ flow_x_ch, long long flow_x_ch_bstride) {
     const int b = blockIdx.y;
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= HW) return;
@@ -169,7 +170,13 @@ __global__ __launch_bounds__(256) void k_softmax_blend(const float* __restrict__
     const size_t o = (size_t)b * HW + p;
     refined[o] = r;
     if (delta) delta[o] = r - disp_q[o];
-    if (coords1) coords1[o] = (float)(p % W) - r;
+    const float xf = (float)(p % W);
+    const float c1 = xf - r;
+    if (coords1) coords1[o] = c1;
+    // next iteration's motion-encoder input, coords1 - coords0 (tc_stereo.py:180): contiguous copy for the 7x7 stem and
+    // a copy straight into channel 127 of the motion feature buffer (update.py:126)
+    if (flow_x) flow_x[o] = c1 - xf;
+    if (flow_x_ch) flow_x_ch[(size_t)b * flow_x_ch_bstride + p] = c1 - xf;
 }
 
 // tc_stereo.py:75-88 (factor 4) on flow = -disp, clipped like the returned dict (tc_stereo.py:223-224)
@@ -258,11 +265,13 @@ int tcs_propagate_disparity(const float* grad, const float* disp, int B, int H, 
 }
 
 int tcs_softmax_blend(const float* logits9, const float* cand, int cand_ctot, const float* disp_q,
-                      int B, int H, int W, float* refined, float* delta_disp, float* coords1, tcs_stream_t stream) {
+                      int B, int H, int W, float* refined, float* delta_disp, float* coords1, float* flow_x, float* flow_x_ch,
+                      long long flow_x_ch_bstride, tcs_stream_t stream) {
     if (!logits9 || !cand || !refined || cand_ctot < 9 || B <= 0 || B > 65535 || H <= 0 || W <= 0) return TCS_EINVAL;
     if (delta_disp && !disp_q) return TCS_EINVAL;
+    if (flow_x_ch && flow_x_ch_bstride < (long long)H * W) return TCS_EINVAL;
     hipLaunchKernelGGL(k_softmax_blend, dim3(tcs_cdiv((long long)H * W, 256), B), dim3(256), 0, tcs_stream(stream),
-                       logits9, cand, cand_ctot, disp_q, W, H * W, refined, delta_disp, coords1);
+                       logits9, cand, cand_ctot, disp_q, W, H * W, refined, delta_disp, coords1, flow_x, flow_x_ch, flow_x_ch_bstride);
     return tcs_launch_status();
 }
 

@@ -63,7 +63,7 @@ SIGNATURES = {
     "tcs_disp_gradient_xy": (c_int, [c_fp, c_int, c_int, c_int, c_f, c_fp, c_fp]),
     "tcs_grad_candidates": (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_fp]),
     "tcs_propagate_disparity": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp]),
-    "tcs_softmax_blend": (c_int, [c_fp, c_fp, c_int, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp]),
+    "tcs_softmax_blend": (c_int, [c_fp, c_fp, c_int, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_longlong, c_fp]),
     "tcs_convex_upsample": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp, c_fp]),
     "tcs_avgpool3s2": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp]),
     "tcs_resize_bilinear": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp]),

@@ -257,12 +257,22 @@ def propagate_disparity(grad, disp, out=None):
     return out
 
 
-def softmax_blend(logits9, cand, disp_q=None, want_delta=False, coords1=None, refined=None):
+def softmax_blend(logits9, cand, disp_q=None, want_delta=False, coords1=None, refined=None, flow_x=None, flow_x_channel=None):
+    """`flow_x` [B,1,H,W] and `flow_x_channel` (a one-channel slice t[:, c:c+1] of a contiguous [B,C,H,W] tensor) receive
+    coords1 - x, the next iteration's motion-encoder input."""
     B, _, H, W = _dims4(logits9, "logits")
     refined = _new(logits9, B, 1, H, W) if refined is None else refined
     delta = _new(logits9, B, 1, H, W) if want_delta else None
+    ch_ptr, ch_stride = None, 0
+    if flow_x_channel is not None:
+        if tuple(flow_x_channel.shape) != (B, 1, H, W) or flow_x_channel.stride()[2:] != (W, 1) or flow_x_channel.dtype != torch.float32:
+            raise ValueError("flow_x_channel must be a [B,1,H,W] float32 channel slice with dense rows")
+        if not flow_x_channel.is_cuda:
+            raise RuntimeError("flow_x_channel: CPU tensor (the hot path has no CPU fallback)")
+        ch_ptr, ch_stride = flow_x_channel.data_ptr(), int(flow_x_channel.stride()[0]) if B > 1 else H * W
     nv.check(nv.lib().tcs_softmax_blend(nv.ptr(logits9, "logits"), nv.ptr(cand, "cand"), int(cand.shape[1]), nv.ptr(disp_q), B, H, W,
-                                        nv.ptr(refined), nv.ptr(delta), nv.ptr(coords1), nv.stream()), "tcs_softmax_blend")
+                                        nv.ptr(refined), nv.ptr(delta), nv.ptr(coords1), nv.ptr(flow_x), ch_ptr, ch_stride, nv.stream()),
+             "tcs_softmax_blend")
     return refined, delta
 
 
