@@ -18,7 +18,9 @@ SOURCES = ["tcs_corr.hip", "tcs_warp.hip", "tcs_stencil.hip", "tcs_conv.hip", "t
 # -amdgpu-kernarg-preload-count: the first 16 kernarg dwords of kernels with scalar parameters arrive in SGPRs at wave
 # launch instead of through an s_load round trip (measured on the latency-bound corr lookup: 2.94 -> 2.81 us per launch)
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function",
-         "-mllvm", "-amdgpu-kernarg-preload-count=16"]
+         "-mllvm", "-amdgpu-kernarg-preload-count=16",
+         # accumulators of the MFMAs in ordinary VGPRs (no v_accvgpr moves around the epilogues): 0.3 % on the frame
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _hipcc() -> str:
