@@ -7,7 +7,7 @@ A "step" is one stereo pair of a synthetic 10-frame 640x480 sequence through `TC
 wraps).  Inputs are resident in HBM before the timed region.  One process per GPU, one independent
 sequence per rank (no data-path collective; one all_gather of EPE statistics at the end).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a torchrun environment: spawns N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 with `roofline` (corr lookup, device-clock stamps in the timed region) and
@@ -170,8 +170,10 @@ def lookup_roofline(probe, snapshots, burst_us, pixels):
     return roof
 
 
-def cpu_baseline(W, seq, gpu_preds, n_frames=2):
-    """The CPU oracle ("port" of the reference's fp32 CPU path) on the first frames of the same clip."""
+def cpu_baseline(W, seq, gpu_preds, n_frames=3):
+    """The CPU oracle ("port" of the reference's fp32 CPU path) on the first frames of the same clip: one untimed
+    warm-up frame (thread pool, allocator, first-touch), then `n_frames` frames timed one by one; the value is
+    1 / median frame time (1 warm-up + median of >= 3)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import tcs_oracle as oracle
     from tcs_mi355.harness import run_sequence
@@ -182,17 +184,67 @@ def cpu_baseline(W, seq, gpu_preds, n_frames=2):
         avail = os.cpu_count() or 1
     cores = max(1, min(avail, os.cpu_count() or 1, int(os.environ.get("TCS_BENCH_CPU_THREADS", "16"))))
     torch.set_num_threads(cores)
-    log(f"cpu baseline: oracle on {cores} threads, {n_frames} frames ...")
+    log(f"cpu baseline: oracle on {cores} threads, 1 warm-up + {n_frames} timed frames ...")
+    stamps = []
+
+    def fwd(a, b, **kw):
+        out = oracle.tc_stereo_forward(W, a, b, iters=kw["iters"], params=kw["params"])
+        stamps.append(time.perf_counter())
+        return out
+
+    warm = type(seq)(seq.frames[:1], seq.K, seq.baseline)
+    run_sequence(fwd, warm, iters=ITERS, device=torch.device("cpu"))
     sub = type(seq)(seq.frames[:n_frames], seq.K, seq.baseline)
     preds = []
+    stamps.clear()
     t0 = time.perf_counter()
-    run_sequence(lambda a, b, **kw: oracle.tc_stereo_forward(W, a, b, iters=kw["iters"], params=kw["params"]), sub, iters=ITERS,
-                 device=torch.device("cpu"), collect=preds)
-    dt = time.perf_counter() - t0
+    run_sequence(fwd, sub, iters=ITERS, device=torch.device("cpu"), collect=preds)
+    times = np.diff(np.array([t0] + stamps))
+    med = float(np.median(times))
     epes = [float((g.cpu() - p).abs().mean()) for g, p in zip(gpu_preds, preds)]
-    return {"value": round(n_frames / dt, 4), "unit": "stereo-pairs/s", "cores": cores, "kind": "port",
-            "sample": f"first {n_frames} frames of the same 640x480 clip, 32 iters, oracle/tcs_oracle.py on torch CPU fp32, "
-                      f"{torch.get_num_threads()} threads"}, epes
+    return {"value": round(1.0 / med, 4), "unit": "stereo-pairs/s", "cores": cores, "kind": "port",
+            "frame_seconds": [round(float(t), 3) for t in times],
+            "sample": f"median of the first {n_frames} frames of the same 640x480 clip after 1 untimed warm-up frame, 32 iters, "
+                      f"oracle/tcs_oracle.py on torch CPU fp32, {torch.get_num_threads()} threads"}, epes
+
+
+def spawn_ranks(a, argv):
+    """`python bench.py --gpus N` outside torchrun: start N fresh rank processes (one per GPU, RCCL over xGMI) BEFORE this
+    process has made any GPU call, relay rank 0's JSON line, exit with the worst return code.  The parent never touches
+    the GPU (a process that has initialised HIP must not exec or fork GPU workers on this pool)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit(f"rank return codes {rcs}")
+
+
+def dry_run(a, tdist, rank, world):
+    """The multi-rank plumbing of main() with the model replaced by a sleep: what the world-size-2 gloo test drives."""
+    import torch.distributed as dist
+    tdist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    tdist.barrier()
+    elapsed = time.perf_counter() - t0
+    vecs = tdist.gather_vectors(np.array([a.steps, elapsed], np.float64))
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_frames": [int(v[0]) for v in vecs],
+                          "dist_world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                          "dist_backend": dist.get_backend() if dist.is_initialized() else None,
+                          "value": sum(int(v[0]) for v in vecs) / max(float(v[1]) for v in vecs)}), flush=True)
 
 
 def main():
@@ -208,18 +260,27 @@ def main():
                     help="frame size other than BASELINE configs[1]'s 480x640, e.g. 375x1242 for configs[4] (KITTI raw latency)")
     ap.add_argument("--batched-leg", type=int, default=4,
                     help="after the timed run, also time this many sequences per launch (reported under batched_leg; 0/1 = skip)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher rehearsal without a GPU: ranks, rendezvous, barrier and the statistics gather only (tests)")
     a = ap.parse_args()
 
     global HEIGHT, WIDTH
     if a.size:
         HEIGHT, WIDTH = (int(v) for v in a.size.lower().split("x"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(a, sys.argv[1:])           # before anything touches the GPU
     from tcs_mi355 import dist as tdist
+    rank, world, local = tdist.init_from_env("gloo" if a.dry_run else None)
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torchrun --nproc-per-node {a.gpus}, or without "
+                         f"a torchrun environment (bench.py then starts the ranks itself)")
+    if a.dry_run:
+        return dry_run(a, tdist, rank, world)
     from tcs_mi355 import native, synth
-    rank, world, local = tdist.init_from_env()
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if not a.eager:
+        os.environ["TCS_MI355_GRAPH_STRICT"] = "1"   # a failed capture must fail the run, not degrade it to eager launches
     native.lib()
     if os.environ.get("TCS_MI355_DIST_BACKEND") == "gloo":        # rehearsal: several ranks may share a GPU
         local = local % torch.cuda.device_count()
@@ -255,6 +316,10 @@ def main():
         tdist.barrier()
         elapsed = time.perf_counter() - t0
     ops.LOOKUP_PROBE = None
+    graphs = getattr(model, "_graphs", None)
+    if not a.eager and (graphs is None or graphs.fell_back or any(v is None for v in graphs.cache.values())):
+        raise SystemExit("bench.py: a frame ran with eager launches although HIP-graph replay was requested "
+                         f"(fell_back={getattr(graphs, 'fell_back', None)}); refusing to report it as graph replay")
     with torch.no_grad():
         try:
             roof = lookup_roofline(probe, snaps, lookup_burst_us(dev, S), S * _quarter(HEIGHT) * _quarter(WIDTH))
@@ -276,11 +341,11 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
             from tcs_mi355.harness import run_sequence
-            sub = type(seq)(seq.frames[:2], seq.K, seq.baseline)
+            sub = type(seq)(seq.frames[:3], seq.K, seq.baseline)
             gpu_preds = []
             log("accuracy sample on the GPU")
             run_sequence(model, sub, iters=ITERS, device=dev, collect=gpu_preds)
-            cpu, epes = cpu_baseline(W, seq, gpu_preds, 2)
+            cpu, epes = cpu_baseline(W, seq, gpu_preds, 3)
             epe_vs_oracle = [round(e, 6) for e in epes]
         except Exception as e:                    # report the failure, keep the headline line
             log(f"cpu baseline leg failed: {type(e).__name__}: {e}")
@@ -336,6 +401,8 @@ def main():
                        "launch": "eager" if a.eager else "hip-graph replay"},
             "roofline": roof, "cpu_baseline": cpu, "epe_vs_oracle_first_frames": epe_vs_oracle, "batched_leg": batched,
             "ranks_frames": [int(v[0]) for v in vecs],
+            "dist_world_size": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+            "dist_backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
         }
         print(json.dumps(line), flush=True)
 

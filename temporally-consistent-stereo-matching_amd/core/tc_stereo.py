@@ -4,8 +4,8 @@ Same constructor (an argparse-style Namespace), same sub-module names (reference
 with strict=True), same `forward(image1, image2, iters, params, test_mode, frame_id)` signature and
 the same test-mode output dict, so evaluate_stereo.py's loop (evaluate_stereo.py:170-197) runs
 unchanged.  What differs is underneath: correlation build/lookup, the temporal warp, the GRU update
-step and every stencil are hand-written HIP kernels for gfx950 (libtcs_mi355.so); only the feature
-extractor and the once-per-frame U-Nets remain PyTorch-ROCm modules.
+step, both U-Nets, every stencil and the feature extractor's convolutions are hand-written HIP kernels
+for gfx950 (libtcs_mi355.so); PyTorch-ROCm owns tensors, streams and graph capture.
 
 Inference only: `test_mode=False` (training outputs and losses, train_stereo.py) is out of scope.
 There is no CPU path: tensors must live on a HIP device and the library must be built.
@@ -77,6 +77,10 @@ class TCStereo(nn.Module):
     def fuse_previous_current_hidden_state(self, net_list, warp_net_list):
         return [fuse(n, w) for n, w, fuse in zip(net_list, warp_net_list, self.previous_current_hideen_fuse)]
 
+    def _weights_epoch(self):
+        """Changes whenever a parameter tensor is replaced or written in place (load_state_dict, .copy_, optimiser step)."""
+        return hash(tuple((p.data_ptr(), p._version) for p in self.parameters()))
+
     # -----------------------------------------------------------------------------------------
     def _extract(self, image1, image2):
         a = self.args
@@ -113,7 +117,8 @@ class TCStereo(nn.Module):
         if self.use_hip_graph:
             if getattr(self, "_graphs", None) is None:
                 from tcs_mi355.graph import FrameGraphs
-                self._graphs = FrameGraphs(self._frame)
+                self._graphs = FrameGraphs(self._frame, epoch_fn=self._weights_epoch,
+                                           strict=os.environ.get("TCS_MI355_GRAPH_STRICT", "0") == "1")
             return self._graphs(image1, image2, iters, temporal)
         return self._frame(image1, image2, iters, temporal)
 

@@ -2,12 +2,11 @@
 
 Module and parameter names equal the reference's, so `load_state_dict(strict=True)` accepts its
 checkpoints; `nn.Conv2d` objects are kept as parameter containers only.  Their forward passes run
-through `tcs_conv2d` (fp32 MFMA implicit GEMM with virtual concat and fused epilogues), so a
-ConvGRU is two launches instead of ~15 ATen ops, and the 24 host-synchronising NaN asserts per
-iteration of the reference (update.py:27-35,58-67,78-86,155-158) are gone.
-
-Still on PyTorch-ROCm (MIOpen) for now: the stride-2 convs and the transposed-conv + InstanceNorm
-up-blocks of the two U-Nets (DispGradPredictor, DisparityCompletor) — SURVEY.md §8f N3/N4.
+through `tcs_conv2d` (implicit GEMM on the matrix cores with virtual concat and fused epilogues), so
+a ConvGRU is two launches instead of ~15 ATen ops, and the 24 host-synchronising NaN asserts per
+iteration of the reference (update.py:27-35,58-67,78-86,155-158) are gone.  Every layer — including
+the stride-2 convs, the transposed-conv + InstanceNorm up-blocks of both U-Nets and the
+DisparityCompletor — runs on the HIP library; nothing here calls MIOpen.
 """
 import os
 
@@ -32,6 +31,8 @@ CONV_MATH = os.environ.get("TCS_MI355_MATH", "f16x3")
 def packed(conv: nn.Conv2d) -> ops.PackedConv:
     w, b = conv.weight, conv.bias
     math = getattr(conv, "_tcs_math", None) or CONV_MATH
+    if conv.stride == (2, 2):
+        math = "f16x3"          # stride-2 convolutions exist on the fp16-split kernel only (also under TCS_MI355_MATH=f32)
     key = (w.data_ptr(), w._version, w.device, None if b is None else (b.data_ptr(), b._version), math)
     hit = getattr(conv, "_tcs_packed", None)
     if hit is None or hit[0] != key:
@@ -45,11 +46,6 @@ def packed(conv: nn.Conv2d) -> ops.PackedConv:
 
 def hip_conv(conv, srcs, act="none", **kw):
     return ops.conv2d(packed(conv), [s.float().contiguous() for s in srcs], act=act, stride=conv.stride[0], **kw)
-
-
-def hip_ok_stride2() -> bool:
-    """Stride-2 and transposed convolutions exist only on the fp16-split kernel; with TCS_MI355_MATH=f32 they stay on MIOpen."""
-    return CONV_MATH == "f16x3"
 
 
 def packed_deconv(deconv: nn.ConvTranspose2d) -> ops.PackedConv:
@@ -279,14 +275,7 @@ class DispGradPredictor(nn.Module):
         self.conv_out = nn.Sequential(_conv(64, 64, 3), relu())
 
     def _up(self, block: Conv2x_IN, x, rem):
-        """Conv2x_IN: all-HIP with the fp16-split kernels; with TCS_MI355_MATH=f32 the transposed conv + InstanceNorm
-        stay on MIOpen and only the 3x3 conv2 runs on MFMA."""
-        if hip_ok_stride2():
-            return hip_up_block(block, x, rem)
-        y = block.conv1(x)
-        if y.shape != rem.shape:
-            y = F.interpolate(y, size=rem.shape[-2:], mode="nearest")
-        return hip_conv(block.conv2.conv, [(y + rem)], act="leaky")
+        return hip_up_block(block, x, rem)
 
     def forward(self, disp_grad, disp, clist, g5=None, cands=None):
         """`g5`, when given, is 5*disp_grad already produced by the gradient kernel (saves an elementwise launch)."""
@@ -298,10 +287,9 @@ class DispGradPredictor(nn.Module):
         x4_grad, x4_cand = fork_join([lambda: hip_seq(self.conv_grad_stem, [g5]),
                                       lambda: hip_seq(self.conv_grad_candidate_stem, [cands])], site="stems")
         x4 = hip_seq(self.conv_4_4, [x4_grad, x4_cand, clist[0]])
-        s2 = hip_ok_stride2()
-        x8 = hip_seq(self.conv_4_8, [x4]) if s2 else self.conv_4_8(x4)          # 3x3 stride 2
+        x8 = hip_seq(self.conv_4_8, [x4])                                       # 3x3 stride 2
         x8 = hip_seq(self.conv_8_8, [x8, clist[1]])
-        x16 = hip_seq(self.conv_8_16, [x8]) if s2 else self.conv_8_16(x8)       # 3x3 stride 2
+        x16 = hip_seq(self.conv_8_16, [x8])                                     # 3x3 stride 2
         x16 = hip_seq(self.conv_16_16, [x16, clist[2]])
         x8_up = self._up(self.conv_16_8, x16, x8)
         x4_up = self._up(self.conv_8_4, x8_up, x4)
@@ -359,7 +347,7 @@ class DispRefine(nn.Module):
 
 
 # ---------------------------------------------------------------------------------------------
-# temporal disparity completion (once per frame; PyTorch-ROCm for now — SURVEY.md §8a row a9)
+# temporal disparity completion (once per frame)
 # ---------------------------------------------------------------------------------------------
 class DisparityCompletor(nn.Module):
     def __init__(self):
@@ -406,20 +394,6 @@ class DisparityCompletor(nn.Module):
         return completed, disp_mono * 10, w, nets
 
     def forward(self, disp, cost, mask, context_list):
-        if hip_ok_stride2() and disp.is_cuda:
-            return self._forward_hip(disp, cost, mask, [c.float().contiguous() for c in context_list])
-        d = disp / 10
-        x4_disp = self.conv_disp_fuse(torch.cat((self.conv_disp_stem(d), self.conv_cost_stem(cost),
-                                                 self.conv_mask_stem(mask - 0.5)), 1))
-        x4 = self.conv_4_4(torch.cat((x4_disp, context_list[0]), 1))
-        x8 = self.conv_8_8(torch.cat((self.conv_4_8(x4), context_list[1]), 1))
-        x16_out = self.conv_16_16(torch.cat((self.conv_8_16(x8), context_list[2]), 1))
-        x8_out = self.conv_16_8(x16_out, x8)
-        x4_out = self.conv_8_4(x8_out, x4)
-        disp_mono = self.disp_head(x4_out)
-        w = self.w_head(x4_out)
-        completed = (w * d + (1 - w) * disp_mono) * 10
-        nets = [head(torch.cat((x, c), 1)) for head, x, c in
-                ((self.conv_out4_disp, x4_out, context_list[0]), (self.conv_out8_disp, x8_out, context_list[1]),
-                 (self.conv_out16_disp, x16_out, context_list[2]))]
-        return completed, disp_mono * 10, w, nets
+        if not disp.is_cuda:
+            raise RuntimeError("DisparityCompletor: CPU tensor (the hot path has no CPU fallback)")
+        return self._forward_hip(disp, cost, mask, [c.float().contiguous() for c in context_list])

@@ -1,6 +1,7 @@
 """Conv + InstanceNorm + LeakyReLU building blocks of the two U-Nets (reference:
-core/utils/basic_layers.py).  These stay on PyTorch-ROCm/MIOpen:
-only the module/parameter names matter here, so that reference checkpoints load by key."""
+core/utils/basic_layers.py).  Parameter containers: the hot path runs them through the HIP library
+(core/update.py:hip_up_block — transposed conv as a 3x3 conv + pixel-shuffle epilogue, k_instance_norm); the
+`forward` methods below are plain-PyTorch equivalents kept for API parity and are not called by TCStereo."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F

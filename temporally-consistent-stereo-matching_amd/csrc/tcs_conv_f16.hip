@@ -18,7 +18,6 @@
 // The weight image is produced once at pack time (tcs_pack_conv_weight_f16x3) in exactly this order,
 // so staging weights is a straight 16-byte-per-lane copy; activations are split on the fly.
 #include "tcs_conv_common.h"
-#include <stdlib.h>
 
 #ifdef TCS_CONV_STAMPS
 // Diagnostic build only (lib/libtcs_mi355_stamps.so): per-phase shader-clock sums of the K loop, per wave.
@@ -49,18 +48,17 @@ __device__ __forceinline__ void split_f16x2(float x0, float x1, half2_t& hi, hal
 }
 
 // MT = 32-wide output-channel tiles per wave, MP = patch rows per wave (block patch = 4*MP rows x 32 columns),
-// KSTEPS = 16-channel MFMA K-steps per LDS chunk, WM = wave groups along the output channels: the block has 4*WM waves
-// and covers 32*MT*WM output channels; wave (row, g) owns patch row(s) `row` and tiles g*MT .. g*MT+MT-1.
+// KSTEPS = 16-channel MFMA K-steps per LDS chunk; the block has ROWS waves and covers 32*MT output channels; wave `row`
+// owns patch row(s) `row`.
 // A wave issues one instruction every ~4-5 cycles, and a chunk costs ~700 non-MFMA instructions per block (loads,
 // fp16 split, LDS traffic) against 27*MT*MP MFMAs per wave: with 4 waves the block is issue-bound at 4-5x the MFMA time
-// (measured with in-kernel stamps, tools/conv_phases.py).  WM = 2 halves the staging work per wave and doubles the
-// waves that share one LDS image.
+// (measured with in-kernel stamps, tools/conv_phases.py).
 // ROWS = waves along the patch rows (patch = ROWS*MP rows): 5 instead of 4 turns the 600- and 300-workgroup grids of the
 // 1/4-scale layers (2.3 and 1.2 workgroups per CU: some CUs carry one more than the others for the whole kernel) into
 // 480 and 240 (at most 2 / 1 per CU).
-template <int KS, int MT, int MP, int KSTEPS, int EPI, int STRIDE = 1, int PF = 1, int WM = 1, int ROWS = 4>
-__global__ __launch_bounds__(64 * ROWS * WM) void k_conv_f16x3(ConvArgs a) {
-    constexpr int NTHREADS = 64 * ROWS * WM, MTB = MT * WM;                    // MTB: cout tiles per block
+template <int KS, int MT, int MP, int KSTEPS, int EPI, int STRIDE = 1, int ROWS = 4>
+__global__ __launch_bounds__(64 * ROWS) void k_conv_f16x3(ConvArgs a) {
+    constexpr int NTHREADS = 64 * ROWS, MTB = MT;                         // MTB: cout tiles per block
     constexpr int HALO = KS / 2, PR = ROWS * MP, IH = STRIDE * PR + KS - STRIDE, IW = STRIDE * 32 + KS - STRIDE, TAPS = KS * KS,
                   IN_CH = IH * IW;
     constexpr int NT = 32 * MTB, KC = 16 * KSTEPS, NG = 2 * KSTEPS;           // NG: 8-channel groups per chunk
@@ -122,9 +120,8 @@ __global__ __launch_bounds__(64 * ROWS * WM) void k_conv_f16x3(ConvArgs a) {
     const size_t w_chunk_units = (size_t)TAPS * nct32 * 128;                   // units per 16-channel k-step
     const size_t w_ct = (size_t)ct * MTB * 128;
 
-    // PF = prefetch distance in chunks: PF register sets hold chunks in flight (set B only exists when PF == 2)
-    float in_regA[PPT * GPT * 8], in_regB[PF == 2 ? PPT * GPT * 8 : 1];
-    u32x4 w_regA[W_PT], w_regB[PF == 2 ? W_PT : 1];
+    float in_regA[PPT * GPT * 8];
+    u32x4 w_regA[W_PT];
 
     // Per-group scalar base pointers of the NEXT chunk to be loaded.  They are computed one phase ahead of their use
     // (right after the previous TCS_LOAD_CHUNK), so the scalar kernarg loads behind conv_src_ptr() land during the MFMA
@@ -277,7 +274,7 @@ __global__ __launch_bounds__(64 * ROWS * WM) void k_conv_f16x3(ConvArgs a) {
     TCS_GROUP_BASES(KC)
     TCS_STORE_CHUNK(in_regA, w_regA, 0)
     __syncthreads();
-    if (PF == 1) {
+    {
         // global loads of chunk i+1 are in flight during the MFMAs of chunk i
 #ifdef TCS_CONV_STAMPS
         unsigned long long ts0, ts1, ts2, ts3, ts4, ts5, acc_t[5] = {0, 0, 0, 0, 0};
@@ -323,30 +320,11 @@ __global__ __launch_bounds__(64 * ROWS * WM) void k_conv_f16x3(ConvArgs a) {
         }
 #ifdef TCS_CONV_STAMPS
         if (lane == 0) {
-            const size_t w_ = ((size_t)blockIdx.x * ROWS * WM + wave_all) % 16384;
+            const size_t w_ = ((size_t)blockIdx.x * ROWS + wave_all) % 16384;
             for (int q = 0; q < 5; ++q) tcs_conv_stamps[w_ * 8 + q] = acc_t[q];
             tcs_conv_stamps[w_ * 8 + 5] = nchunks;
         }
 #endif
-    } else {
-        // two chunks in flight (register sets A and B): a load has two compute phases to land before it is needed.
-        // Used for the narrow tiles, whose MFMA phase is shorter than the memory latency.
-        if (nchunks > 1) TCS_LOAD_CHUNK(in_regA, w_regA, KC)
-        for (int i = 0; i < nchunks; i += 2) {
-            if (i + 2 < nchunks) { TCS_GROUP_BASES((i + 2) * KC) TCS_LOAD_CHUNK(in_regB, w_regB, (i + 2) * KC) }
-            TCS_COMPUTE()                                   // chunk i
-            if (i + 1 >= nchunks) break;
-            __syncthreads();
-            TCS_STORE_CHUNK(in_regA, w_regA, (i + 1) * KC)
-            __syncthreads();
-            if (i + 3 < nchunks) { TCS_GROUP_BASES((i + 3) * KC) TCS_LOAD_CHUNK(in_regA, w_regA, (i + 3) * KC) }
-            TCS_COMPUTE()                                   // chunk i+1
-            if (i + 2 < nchunks) {
-                __syncthreads();
-                TCS_STORE_CHUNK(in_regB, w_regB, (i + 2) * KC)
-                __syncthreads();
-            }
-        }
     }
 #undef TCS_COMPUTE
 #undef TCS_COMPUTE_ASM
@@ -574,212 +552,6 @@ __global__ __launch_bounds__(256 + 64 * NP) void k_conv_f16x3_ws(ConvArgs a) {
     for (int m = 0; m < MT; ++m) conv_epilogue_tile<EPI>(a, b, ct * NT + m * 32 + 4 * half, pix, HW, acc[m], a.w_unscale);
 }
 
-// Buffer descriptor from wave-uniform inputs.  readfirstlane makes the uniformity provable to hipcc; without it every
-// buffer_load is wrapped in a "waterfall" loop (cdna_hip_programming.md T20).
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const float* p, int bytes) {
-    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-    void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
-    return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// Pipelined variant (stride 1): double-buffered LDS, ONE barrier per chunk, buffer loads.
-//   iteration i:  split+store chunk i+1 (registers -> LDS buffer B)  |  issue buffer loads of chunk i+2
-//                 MFMA on chunk i (LDS buffer A)                      |  barrier, swap A/B
-// Loads use raw buffer instructions: the resource lives in SGPRs, the per-thread offset is a VGPR that never
-// changes, the per-channel step goes into the scalar offset — no 64-bit VGPR address temporaries, hence none of the
-// counted vmcnt waits hipcc placed between the global_loads of the first version (1.9k of 5.5k cycles per chunk).
-// ------------------------------------------------------------------------------------------------------------
-template <int KS, int MT, int KSTEPS, int EPI>
-__global__ __launch_bounds__(256) void k_conv_f16x3_db(ConvArgs a) {
-    constexpr int HALO = KS / 2, IH = 4 + KS - 1, IW = 32 + KS - 1, TAPS = KS * KS, IN_CH = IH * IW;
-    constexpr int NT = 32 * MT, KC = 16 * KSTEPS, NG = 2 * KSTEPS;
-    constexpr int IN_BYTES = NG * IN_CH * 16;
-    constexpr int W_UNITS = KSTEPS * TAPS * MT * 2 * 64;
-    constexpr int BUF_BYTES = 2 * IN_BYTES + W_UNITS * 16;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds8[];
-
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bid = blockIdx.x;
-    const int ct = bid % a.nct, patch = bid / a.nct;
-    const int b = blockIdx.y;
-    const int y0 = (patch / a.npx) * 4, x0 = (patch % a.npx) * 32;
-    const int H = a.H, W = a.W;
-    const size_t HW = (size_t)H * W;
-
-    f32x16 acc[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
-
-    constexpr int PARTS = (IN_CH <= 128) ? 2 : 1;
-    constexpr int TPP = 256 / PARTS, PPT = (IN_CH + TPP - 1) / TPP, GPT = NG / PARTS;
-    static_assert(NG % PARTS == 0, "groups must split evenly");
-    const int part = PARTS == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid / TPP);
-    const int tpos = tid - part * TPP;
-    int s_pix[PPT];
-    int s_off[PPT];
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        const int pos = tpos + TPP * k;
-        const int sr = pos / IW, sc = pos - sr * IW;
-        const int gy = y0 - HALO + sr, gx = x0 - HALO + sc;
-        s_pix[k] = pos >= IN_CH ? -2 : ((gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1);
-        s_off[k] = max(s_pix[k], 0) * 4;
-    }
-    constexpr int W_PT = (W_UNITS + 255) / 256;
-    const int nct32 = a.CoutPad / 32;
-    int w_voff[W_PT];
-#pragma unroll
-    for (int j = 0; j < W_PT; ++j) {
-        const int u = min(tid + 256 * j, W_UNITS - 1);
-        const int piece = u / (MT * 128), within = u - piece * (MT * 128);
-        w_voff[j] = (piece * nct32 * 128 + within) * 16;
-    }
-    const int w_chunk_bytes = TAPS * nct32 * 128 * 16;                  // one 16-channel k-step of the packed weights
-    const int w_ct_bytes = ct * MT * 128 * 16;
-    const __amdgpu_buffer_rsrc_t rsrc_w = uniform_rsrc(a.w, a.w_bytes);
-    const int plane_bytes = (int)(HW * 4);
-
-    float in_reg[PPT * GPT * 8];
-    u32x4 w_reg[W_PT];
-
-#define DB_LOAD(C0)                                                                                             \
-    {                                                                                                           \
-        const int wsoff = __builtin_amdgcn_readfirstlane(((C0) / 16) * w_chunk_bytes + w_ct_bytes);             \
-        _Pragma("unroll") for (int j = 0; j < W_PT; ++j)                                                        \
-            w_reg[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff[j], wsoff, 0);                      \
-        _Pragma("unroll") for (int gi = 0; gi < GPT; ++gi) {                                                    \
-            const int g0 = (C0) + (part * GPT + gi) * 8;                                                        \
-            if (a.src_align8) {                                                                                 \
-                const int gc = min(g0, a.Cin - 8);                                                              \
-                const float* sp = a.src[0];                                                                     \
-                int cb = 0, cs = a.src_ch[0];                                                                   \
-                if (gc >= a.src_end[0]) { sp = a.src[1]; cb = a.src_end[0]; cs = a.src_ch[1]; }                 \
-                if (gc >= a.src_end[1]) { sp = a.src[2]; cb = a.src_end[1]; cs = a.src_ch[2]; }                 \
-                if (gc >= a.src_end[2]) { sp = a.src[3]; cb = a.src_end[2]; cs = a.src_ch[3]; }                 \
-                const __amdgpu_buffer_rsrc_t r = uniform_rsrc(sp + (size_t)b * cs * HW, cs * plane_bytes);     \
-                int soff = __builtin_amdgcn_readfirstlane((gc - cb) * plane_bytes);                             \
-                _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                 \
-                    _Pragma("unroll") for (int k = 0; k < PPT; ++k)                                             \
-                        in_reg[(k * GPT + gi) * 8 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, s_off[k], soff, 0)); \
-                    soff += plane_bytes;                                                                        \
-                }                                                                                               \
-            } else {                                                                                            \
-                _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                 \
-                    const int gc = min(g0 + j, a.Cin - 1);                                                      \
-                    const float* sp = a.src[0];                                                                 \
-                    int cb = 0, cs = a.src_ch[0];                                                               \
-                    if (gc >= a.src_end[0]) { sp = a.src[1]; cb = a.src_end[0]; cs = a.src_ch[1]; }             \
-                    if (gc >= a.src_end[1]) { sp = a.src[2]; cb = a.src_end[1]; cs = a.src_ch[2]; }             \
-                    if (gc >= a.src_end[2]) { sp = a.src[3]; cb = a.src_end[2]; cs = a.src_ch[3]; }             \
-                    const __amdgpu_buffer_rsrc_t r = uniform_rsrc(sp + (size_t)b * cs * HW, cs * plane_bytes); \
-                    _Pragma("unroll") for (int k = 0; k < PPT; ++k)                                             \
-                        in_reg[(k * GPT + gi) * 8 + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, s_off[k], __builtin_amdgcn_readfirstlane((gc - cb) * plane_bytes), 0)); \
-                }                                                                                               \
-            }                                                                                                   \
-        }                                                                                                       \
-    }
-#define DB_STORE(BUF, C0)                                                                                       \
-    {                                                                                                           \
-        unsigned char* s_hi = lds8 + (BUF) * BUF_BYTES;                                                         \
-        unsigned char* s_lo = s_hi + IN_BYTES;                                                                  \
-        unsigned char* s_wt = s_hi + 2 * IN_BYTES;                                                              \
-        _Pragma("unroll") for (int k = 0; k < PPT; ++k) {                                                       \
-            if (s_pix[k] > -2) {                                                                                \
-                const bool pix_ok = s_pix[k] >= 0;                                                              \
-                _Pragma("unroll") for (int gi = 0; gi < GPT; ++gi) {                                            \
-                    const int grp = part * GPT + gi;                                                            \
-                    const int gq = (C0) + grp * 8;                                                              \
-                    half8 hi8, lo8;                                                                             \
-                    _Pragma("unroll") for (int j = 0; j < 8; j += 2) {                                          \
-                        half2_t h2, l2;                                                                         \
-                        const float x0_ = (pix_ok && gq + j < a.Cin) ? in_reg[(k * GPT + gi) * 8 + j] : 0.f;    \
-                        const float x1_ = (pix_ok && gq + j + 1 < a.Cin) ? in_reg[(k * GPT + gi) * 8 + j + 1] : 0.f; \
-                        split_f16x2(x0_, x1_, h2, l2);                                                          \
-                        hi8[j] = h2[0]; hi8[j + 1] = h2[1]; lo8[j] = l2[0]; lo8[j + 1] = l2[1];                 \
-                    }                                                                                           \
-                    const size_t unit = (size_t)grp * IN_CH + tpos + TPP * k;                                   \
-                    *reinterpret_cast<half8*>(s_hi + unit * 16) = hi8;                                          \
-                    *reinterpret_cast<half8*>(s_lo + unit * 16) = lo8;                                          \
-                }                                                                                               \
-            }                                                                                                   \
-        }                                                                                                       \
-        _Pragma("unroll") for (int j = 0; j < W_PT; ++j) {                                                      \
-            const int u = tid + 256 * j;                                                                        \
-            if (u < W_UNITS) *reinterpret_cast<u32x4*>(s_wt + (size_t)u * 16) = w_reg[j];                       \
-        }                                                                                                       \
-    }
-    // one (k-step, tap): 2 input fragments + 2*MT weight fragments (hi, lo), each ONE ds_read_b128
-    struct DbFrag { half8 b_hi, b_lo, a_hi[MT], a_lo[MT]; };
-#define DB_FETCH(F, STEP)                                                                                       \
-    {                                                                                                           \
-        const int ks_ = (STEP) / TAPS, t_ = (STEP) % TAPS, dy_ = t_ / KS, dx_ = t_ % KS;   /* constants after unrolling */ \
-        const size_t boff = ((size_t)(2 * ks_ + half) * IN_CH + (wave + dy_) * IW + dx_ + l31) * 16;            \
-        F.b_hi = *reinterpret_cast<const half8*>(s_hi + boff);                                                  \
-        F.b_lo = *reinterpret_cast<const half8*>(s_lo + boff);                                                  \
-        _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                        \
-            const unsigned char* wt = s_wt + ((size_t)((ks_ * TAPS + t_) * MT + m) * 128 + lane) * 16;          \
-            F.a_hi[m] = *reinterpret_cast<const half8*>(wt);                                                    \
-            F.a_lo[m] = *reinterpret_cast<const half8*>(wt + 1024);                                             \
-        }                                                                                                       \
-    }
-#define DB_MMA(F)                                                                                               \
-    _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                            \
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_lo[m], F.b_hi, acc[m], 0, 0, 0);                    \
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_hi[m], F.b_lo, acc[m], 0, 0, 0);                    \
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_hi[m], F.b_hi, acc[m], 0, 0, 0);                    \
-    }
-    // Software pipeline over the NSTEP = KSTEPS*TAPS steps: the 2+2*MT ds_read_b128 of step i+1 are issued BEFORE the
-    // 3*MT MFMAs of step i (sched_group_barrier pins that order), so LDS latency hides behind the matrix pipe.
-#define DB_STEP(FA, FB, I)                                                                                      \
-    if ((I) + 1 < NSTEP) DB_FETCH(FB, ((I) + 1 < NSTEP ? (I) + 1 : 0))                                          \
-    DB_MMA(FA)                                                                                                  \
-    if ((I) + 1 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * MT, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT, 0);
-#define DB_COMPUTE(BUF)                                                                                         \
-    {                                                                                                           \
-        const unsigned char* s_hi = lds8 + (BUF) * BUF_BYTES;                                                   \
-        const unsigned char* s_lo = s_hi + IN_BYTES;                                                            \
-        const unsigned char* s_wt = s_hi + 2 * IN_BYTES;                                                        \
-        constexpr int NSTEP = KSTEPS * TAPS;                                                                    \
-        DbFrag f0, f1;                                                                                          \
-        DB_FETCH(f0, 0)                                                                                         \
-        _Pragma("unroll") for (int i = 0; i < NSTEP; i += 2) {                                                  \
-            DB_STEP(f0, f1, i)                                                                                  \
-            if (i + 1 < NSTEP) { DB_STEP(f1, f0, i + 1) }                                                       \
-        }                                                                                                       \
-    }
-
-    const int nchunks = (a.Cin + KC - 1) / KC;
-    DB_LOAD(0)
-    DB_STORE(0, 0)
-    if (nchunks > 1) DB_LOAD(KC)
-    __syncthreads();
-    for (int i = 0; i < nchunks; ++i) {
-        const int cur = i & 1;
-        if (i + 1 < nchunks) DB_STORE(cur ^ 1, (i + 1) * KC)        // registers (chunk i+1) -> the other buffer
-        if (i + 2 < nchunks) DB_LOAD((i + 2) * KC)                   // in flight during this chunk's MFMAs and the next store
-        DB_COMPUTE(cur)
-        __syncthreads();
-    }
-#undef DB_LOAD
-#undef DB_STORE
-#undef DB_COMPUTE
-#undef DB_STEP
-#undef DB_MMA
-#undef DB_FETCH
-
-    const int px = x0 + l31, py = y0 + wave;
-    if (px >= W || py >= H) return;
-    const size_t pix = (size_t)py * W + px;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) conv_epilogue_tile<EPI>(a, b, ct * NT + m * 32 + 4 * half, pix, HW, acc[m], a.w_unscale);
-}
-
 // OIHW fp32 weights -> the LDS image order, split into (hi, lo) halves after scaling by 2^scale_log2.
 // unit (16 B = 8 halves) index: ((((kchunk16 * TAPS + t) * nct32 + ct32) * 2 + part) * 64 + h*32 + r)
 __global__ __launch_bounds__(256) void k_pack_weight_f16x3(const float* __restrict__ w, int Cout, int Cin, int taps, int nchunk16,
@@ -806,18 +578,18 @@ __global__ __launch_bounds__(256) void k_pack_weight_f16x3(const float* __restri
     packed[u] = *reinterpret_cast<uint4*>(&v);
 }
 
-template <int KS, int MT, int MP, int KSTEPS, int EPI, int STRIDE = 1, int PF = 1, int WM = 1, int ROWS = 4>
+template <int KS, int MT, int MP, int KSTEPS, int EPI, int STRIDE = 1, int ROWS = 4>
 static int launch_f16(ConvArgs& a, hipStream_t s) {
     constexpr int IH = STRIDE * ROWS * MP + KS - STRIDE, IW = STRIDE * 32 + KS - STRIDE, TAPS = KS * KS;
-    const size_t lds = (size_t)2 * (2 * KSTEPS) * IH * IW * 16 + (size_t)KSTEPS * TAPS * MT * WM * 2 * 1024;
-    auto kern = k_conv_f16x3<KS, MT, MP, KSTEPS, EPI, STRIDE, PF, WM, ROWS>;
+    const size_t lds = (size_t)2 * (2 * KSTEPS) * IH * IW * 16 + (size_t)KSTEPS * TAPS * MT * 2 * 1024;
+    auto kern = k_conv_f16x3<KS, MT, MP, KSTEPS, EPI, STRIDE, ROWS>;
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return TCS_ELAUNCH;
     }
     a.npatch = a.npx * tcs_cdiv(a.H, ROWS * MP);
-    a.nct = (a.CoutPad / 32) / (MT * WM);
-    hipLaunchKernelGGL(kern, dim3(a.npatch * a.nct, a.B), dim3(64 * ROWS * WM), lds, s, a);
+    a.nct = (a.CoutPad / 32) / MT;
+    hipLaunchKernelGGL(kern, dim3(a.npatch * a.nct, a.B), dim3(64 * ROWS), lds, s, a);
     return tcs_launch_status();
 }
 
@@ -836,94 +608,29 @@ static int launch_f16_ws(ConvArgs& a, hipStream_t s) {
     return tcs_launch_status();
 }
 
-// tuning knobs (read once): TCS_F16_MT / TCS_F16_MP in {1,2}, TCS_F16_KSTEPS in {1,2}; 0 = heuristic
-static int env_int(const char* name) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : 0;
-}
-
-template <int KS, int MT, int KSTEPS, int EPI>
-static int launch_f16_db(ConvArgs& a, hipStream_t s) {
-    constexpr int IH = 4 + KS - 1, IW = 32 + KS - 1, TAPS = KS * KS;
-    const size_t lds = 2 * ((size_t)2 * (2 * KSTEPS) * IH * IW * 16 + (size_t)KSTEPS * TAPS * MT * 2 * 1024);
-    auto kern = k_conv_f16x3_db<KS, MT, KSTEPS, EPI>;
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return TCS_ELAUNCH;
-    }
-    a.npatch = a.npx * tcs_cdiv(a.H, 4);
-    a.nct = (a.CoutPad / 32) / MT;
-    hipLaunchKernelGGL(kern, dim3(a.npatch * a.nct, a.B), dim3(256), lds, s, a);
-    return tcs_launch_status();
-}
-
 template <int KS, int EPI>
 static int launch_f16_tile(ConvArgs& a, hipStream_t s) {
-    static const int force_mt = env_int("TCS_F16_MT"), force_mp = env_int("TCS_F16_MP"), force_ks = env_int("TCS_F16_KSTEPS");
+    // Tile choice by grid size only (no environment knobs: the library keeps no mutable global state).
     const int nct32 = a.CoutPad / 32;
     const long long px_tiles = (long long)a.npx * tcs_cdiv(a.H, 4) * a.B;           // 128-pixel patches
     // widest tile (most register reuse of LDS operands) that still leaves >= 2 blocks per CU
     int mt = (nct32 % 2 == 0 && px_tiles * (nct32 / 2) >= 512) ? 2 : 1;
-    int mp = 1;
-    if (force_mt) mt = (force_mt == 2 && nct32 % 2 == 0) ? 2 : 1;
-    if (force_mp) mp = force_mp == 2 ? 2 : 1;
-    // TCS_F16_DB=1 selects the double-buffered / buffer-load pipeline (k_conv_f16x3_db).  Measured on MI355X it ties or
-    // trails the single-buffer kernel on every layer shape of the model, so it is opt-in.
-    // Wave-specialised kernel (k_conv_f16x3_ws) for the layers that cannot fill the chip: with <= 1-2 blocks per CU the
-    // per-chunk latency chain of the plain kernel is exposed, and overlapping staging with the MFMAs gains 10-18 %
-    // (tools/bench_conv.py: 128->128 at 1/32 scale 15.9 -> 13.5 us, gru16.zr 57.6 -> 50.9 us); on full grids it ties or loses.
-    // TCS_F16_WS = 4 / 8 forces it (producer waves), -1 disables it.
-    // 5-row patches when they balance the grid better: efficiency = workgroups / (256 * rounds of one-per-CU)
-    static const int force_rows = env_int("TCS_F16_ROWS");      // 4 / 5 force, 0 = by grid balance
-    if (KS == 3 && !force_mp && force_ks != 2 && force_rows != 4) {
+    if (KS == 3) {
+        // 5-row patches when they balance the grid better: efficiency = workgroups / (256 * rounds of one-per-CU).
+        // Measured (tools/bench_conv.py): 32-channel tiles gain 4-8 % (gru08.q 83 -> 77 us, 128->128 32.3 -> 30.9 us), the
+        // 64-channel tiles lose 20 % (gru08.zr 135 -> 163 us), so this is limited to MT = 1.
         const long long wg4 = (long long)a.npx * tcs_cdiv(a.H, 4) * a.B * (nct32 / mt), wg5 = (long long)a.npx * tcs_cdiv(a.H, 5) * a.B * (nct32 / mt);
         const double e4 = (double)wg4 / (256.0 * ((wg4 + 255) / 256)), e5 = (double)wg5 / (256.0 * ((wg5 + 255) / 256));
-        // measured (tools/bench_conv.py): 32-channel tiles gain 4-8 % (gru08.q 83 -> 77 us, 128->128 32.3 -> 30.9 us), the
-        // 64-channel tiles lose 20 % (gru08.zr 135 -> 163 us), so the automatic choice is limited to MT = 1
-        if (force_rows == 5) return mt == 2 ? launch_f16<3, 2, 1, 1, EPI, 1, 1, 1, 5>(a, s) : launch_f16<3, 1, 1, 1, EPI, 1, 1, 1, 5>(a, s);
-        if (mt == 1 && e5 > e4 + 0.05 && wg4 > 400 && wg4 <= 768) return launch_f16<3, 1, 1, 1, EPI, 1, 1, 1, 5>(a, s);
-    }
-    static const int force_ws = env_int("TCS_F16_WS");
-    int use_ws = force_ws;
-    if (force_ws == 0 && KS == 3 && !force_mt && !force_mp) {
+        if (mt == 1 && e5 > e4 + 0.05 && wg4 > 400 && wg4 <= 768) return launch_f16<3, 1, 1, 1, EPI, 1, 5>(a, s);
+        // Wave-specialised kernel (k_conv_f16x3_ws) for the layers that cannot fill the chip: with <= 1-2 blocks per CU the
+        // per-chunk latency chain of the plain kernel is exposed, and overlapping staging with the MFMAs gains 10-18 %
+        // (tools/bench_conv.py: 128->128 at 1/32 scale 15.9 -> 13.5 us, gru16.zr 57.6 -> 50.9 us); on full grids it ties or loses.
         const long long blocks_mt1 = px_tiles * nct32;
-        use_ws = blocks_mt1 <= 200 ? 8 : (blocks_mt1 <= 400 ? 4 : 0);
-        if (use_ws) mt = 1;
+        if (blocks_mt1 <= 200) return launch_f16_ws<3, 1, 1, EPI, 8>(a, s);
+        if (blocks_mt1 <= 400) return launch_f16_ws<3, 1, 1, EPI, 4>(a, s);
+        return mt == 2 ? launch_f16<3, 2, 1, 1, EPI>(a, s) : launch_f16<3, 1, 1, 1, EPI>(a, s);
     }
-    if (use_ws > 0 && mp == 1 && force_ks != 2) {
-        if (KS == 1) {
-            if (use_ws == 8) return mt == 2 ? launch_f16_ws<1, 2, 4, EPI, 8>(a, s) : launch_f16_ws<1, 1, 4, EPI, 8>(a, s);
-            return mt == 2 ? launch_f16_ws<1, 2, 4, EPI, 4>(a, s) : launch_f16_ws<1, 1, 4, EPI, 4>(a, s);
-        }
-        if (use_ws == 8) return mt == 2 ? launch_f16_ws<3, 2, 1, EPI, 8>(a, s) : launch_f16_ws<3, 1, 1, EPI, 8>(a, s);
-        return mt == 2 ? launch_f16_ws<3, 2, 1, EPI, 4>(a, s) : launch_f16_ws<3, 1, 1, EPI, 4>(a, s);
-    }
-    static const int use_db = env_int("TCS_F16_DB") == 1;
-    if (use_db && mp == 1 && force_ks != 2 && a.w_bytes > 0) {
-        if (KS == 1) return mt == 2 ? launch_f16_db<1, 2, 4, EPI>(a, s) : launch_f16_db<1, 1, 4, EPI>(a, s);
-        return mt == 2 ? launch_f16_db<3, 2, 1, EPI>(a, s) : launch_f16_db<3, 1, 1, EPI>(a, s);
-    }
-    if (KS == 1) {
-        static const int force_wm1 = env_int("TCS_F16_WM");
-        if (force_wm1 == 2 && mp == 1 && nct32 % 2 == 0) return launch_f16<1, 1, 1, 4, EPI, 1, 1, 2>(a, s);
-        if (force_wm1 == 4 && mp == 1 && nct32 % 4 == 0) return launch_f16<1, 1, 1, 4, EPI, 1, 1, 4>(a, s);
-        if (mt == 2) return mp == 2 ? launch_f16<1, 2, 2, 4, EPI>(a, s) : launch_f16<1, 2, 1, 4, EPI>(a, s);
-        return mp == 2 ? launch_f16<1, 1, 2, 4, EPI>(a, s) : launch_f16<1, 1, 1, 4, EPI>(a, s);
-    }
-    const int ks = force_ks == 2 ? 2 : 1;
-    if (ks == 2) {
-        if (mt == 2) return mp == 2 ? launch_f16<3, 2, 2, 2, EPI>(a, s) : launch_f16<3, 2, 1, 2, EPI>(a, s);
-        return mp == 2 ? launch_f16<3, 1, 2, 2, EPI>(a, s) : launch_f16<3, 1, 1, 2, EPI>(a, s);
-    }
-    static const int force_wm = env_int("TCS_F16_WM");
-    if (force_wm == 2 && mp == 1 && nct32 % 2 == 0) {          // 8 waves: 64 (MT=1) or 128 (MT=2) output channels per block
-        if (mt == 2 && nct32 % 4 == 0) return launch_f16<3, 2, 1, 1, EPI, 1, 1, 2>(a, s);
-        return launch_f16<3, 1, 1, 1, EPI, 1, 1, 2>(a, s);
-    }
-    if (mt == 2) return mp == 2 ? launch_f16<3, 2, 2, 1, EPI>(a, s) : launch_f16<3, 2, 1, 1, EPI>(a, s);
-    if (mp == 2) return launch_f16<3, 1, 2, 1, EPI>(a, s);
-    static const int pf = env_int("TCS_F16_PF");                 // 2 = two chunks in flight (measured slower on MI355X: kept as a knob)
-    return pf == 2 ? launch_f16<3, 1, 1, 1, EPI, 1, 2>(a, s) : launch_f16<3, 1, 1, 1, EPI>(a, s);
+    return mt == 2 ? launch_f16<1, 2, 1, 4, EPI>(a, s) : launch_f16<1, 1, 1, 4, EPI>(a, s);
 }
 
 template <int EPI>

@@ -5,7 +5,6 @@
 //   P_i[b][h][d][w1] = L_i[b][h][w1][j],  d = ((w1 >> i) - j) mod W_i,  W_i = W >> i,
 // so that the lookup's taps for horizontally adjacent pixels are contiguous along w1.
 #include "tcs_common.h"
-#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -219,17 +218,15 @@ template <int R, int LPB = 4>
 __global__ __launch_bounds__(64 * LPB) void k_corr_lookup(const float* __restrict__ pyr0, const float* __restrict__ pyr1,
                                                      const float* __restrict__ pyr2, const float* __restrict__ pyr3,
                                                      const float* __restrict__ coords_p, float* __restrict__ out_p,
-                                                     int Bn, int Hn, int Wn, int radius_n, unsigned long long* stamps_p, int a_order) {
+                                                     int Bn, int Hn, int Wn, int radius_n, unsigned long long* stamps_p) {
     struct { const float* coords; float* out; unsigned long long* stamps; int B, H, W, radius; } a =
         {coords_p, out_p, stamps_p, Bn, Hn, Wn, radius_n};
     const int lane = threadIdx.x & 63;
-    // LPB pyramid levels per workgroup (one wave each).  Default order: the 4 / LPB workgroups of a 64-pixel group are
-    // neighbours in the grid.  a_order = 1 (TCS_LOOKUP_ORDER=1) is the level-major alternative, workgroup = level_block *
-    // G8 + group with G8 a multiple of 8, which keeps all levels of a group on one XCD; measured equal on HIP events
-    // (2.85 us) and slightly slower on the in-kernel interval (2.58 vs 2.39 us), PMC traffic unchanged.
-    const unsigned G8 = gridDim.x / (4 / LPB);
-    const unsigned grp = a_order ? blockIdx.x % G8 : blockIdx.x / (4 / LPB);
-    const int level = __builtin_amdgcn_readfirstlane((int)(a_order ? blockIdx.x / G8 : blockIdx.x % (4 / LPB)) * LPB + (int)(threadIdx.x >> 6));
+    // LPB pyramid levels per workgroup (one wave each); the 4 / LPB workgroups of a 64-pixel group are neighbours in the
+    // grid.  (A level-major order that keeps all levels of a group on one XCD measured equal on HIP events, 2.85 us, and
+    // slightly slower on the in-kernel interval, 2.58 vs 2.39 us, with unchanged PMC traffic: not kept.)
+    const unsigned grp = blockIdx.x / (4 / LPB);
+    const int level = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % (4 / LPB)) * LPB + (int)(threadIdx.x >> 6));
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();      // first instruction; stored at the end
     const int HW = a.H * a.W;
     const unsigned total = (unsigned)a.B * (unsigned)HW;                      // host checks B*H*W < 2^31
@@ -359,11 +356,7 @@ int tcs_corr_build(const float* fmap1, const float* fmap2, int B, int C, int H, 
 // Pyramid levels per workgroup.  One sequence (300 pixel groups at 640x480) is latency-bound: 1,200 single-wave workgroups
 // spread evenly over the 256 CUs and finish 12 % sooner than 300 four-wave ones (2.96 vs 3.36 us per launch); large grids
 // (several sequences per launch) stream better with four levels per workgroup (7.0 vs 9.6 us at 4 sequences).
-static int lookup_levels_per_block(long long groups) {
-    static const int forced = getenv("TCS_LOOKUP_LPB") ? atoi(getenv("TCS_LOOKUP_LPB")) : 0;
-    if (forced == 1 || forced == 2 || forced == 4) return forced;
-    return groups <= 512 ? 1 : 4;
-}
+static int lookup_levels_per_block(long long groups) { return groups <= 512 ? 1 : 4; }
 
 int tcs_corr_lookup_blocks(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
@@ -382,21 +375,17 @@ int tcs_corr_lookup(const float* pyr0, const float* pyr1, const float* pyr2, con
     a.pyr[0] = pyr0; a.pyr[1] = pyr1; a.pyr[2] = pyr2; a.pyr[3] = pyr3;
     a.coords = coords; a.out = out; a.stamps = stamps; a.B = B; a.H = H; a.W = W; a.radius = radius;
     const int blocks = tcs_cdiv((long long)B * H * W, 64);
-    static const int order = getenv("TCS_LOOKUP_ORDER") ? atoi(getenv("TCS_LOOKUP_ORDER")) : 0;
     const int lpb = lookup_levels_per_block(blocks);
     const int g8 = (blocks + 7) / 8 * 8;
-    if (radius == 4 && lpb == 2)
-        hipLaunchKernelGGL((k_corr_lookup<4, 2>), dim3(g8 * 2), dim3(128), 0, tcs_stream(stream), pyr0, pyr1, pyr2, pyr3, coords, out, B,
-                           H, W, radius, stamps, order);
-    else if (radius == 4 && lpb == 1)
+    if (radius == 4 && lpb == 1)
         hipLaunchKernelGGL((k_corr_lookup<4, 1>), dim3(g8 * 4), dim3(64), 0, tcs_stream(stream), pyr0, pyr1, pyr2, pyr3, coords, out, B,
-                           H, W, radius, stamps, order);
+                           H, W, radius, stamps);
     else if (radius == 4)
         hipLaunchKernelGGL(k_corr_lookup<4>, dim3(g8), dim3(256), 0, tcs_stream(stream), pyr0, pyr1, pyr2, pyr3, coords, out, B, H, W,
-                           radius, stamps, order);
+                           radius, stamps);
     else
         hipLaunchKernelGGL(k_corr_lookup<0>, dim3(g8), dim3(256), 0, tcs_stream(stream), pyr0, pyr1, pyr2, pyr3, coords, out, B, H, W,
-                           radius, stamps, order);
+                           radius, stamps);
     return tcs_launch_status();
 }
 

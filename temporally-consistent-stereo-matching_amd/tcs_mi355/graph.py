@@ -34,9 +34,17 @@ class _Entry:
 
 
 class FrameGraphs:
-    def __init__(self, frame_fn: Callable, warmup: int = 2):
-        self.frame_fn, self.warmup = frame_fn, warmup
+    """`epoch_fn` returns a value that changes whenever a model parameter is replaced or written in place
+    (`load_state_dict`, an optimiser step): a captured graph holds the packed weight images of the moment of capture,
+    so every entry is dropped and re-captured when it changes.  `fell_back` counts the frames that ran eagerly because
+    a capture failed; `strict=True` turns such a failure into an error instead (bench.py, tests)."""
+
+    def __init__(self, frame_fn: Callable, warmup: int = 2, epoch_fn: Optional[Callable[[], object]] = None, strict: bool = False):
+        self.frame_fn, self.warmup, self.epoch_fn, self.strict = frame_fn, warmup, epoch_fn, strict
         self.cache: Dict[tuple, Optional[_Entry]] = {}
+        self.epoch = epoch_fn() if epoch_fn is not None else None
+        self.fell_back = 0
+        self.captures = 0
 
     def _key(self, image1, iters, flat):
         return (tuple(image1.shape), image1.device.index, int(iters), tuple(tuple(t.shape) for t in flat))
@@ -55,19 +63,28 @@ class FrameGraphs:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 out = run()
+            self.captures += 1
             return _Entry(g, static_in, out)
         except Exception as e:  # capture is an optimisation: the eager HIP path computes the same thing
+            if self.strict:
+                raise
             warnings.warn(f"HIP graph capture failed ({type(e).__name__}: {e}); running this shape with eager launches")
             torch.cuda.synchronize()
             return None
 
     def __call__(self, image1, image2, iters, temporal):
         flat = _flatten(temporal)
+        if self.epoch_fn is not None:
+            now = self.epoch_fn()
+            if now != self.epoch:                  # weights changed: the captured packed-weight images are stale
+                self.cache.clear()
+                self.epoch = now
         key = self._key(image1, iters, flat)
         if key not in self.cache:
             self.cache[key] = self._capture(image1, image2, iters, flat)
         e = self.cache[key]
         if e is None:
+            self.fell_back += 1
             return self.frame_fn(image1, image2, iters, temporal)
         for dst, src in zip(e.static_in, [image1, image2, *flat]):
             dst.copy_(src)

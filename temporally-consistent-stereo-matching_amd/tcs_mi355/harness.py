@@ -38,11 +38,13 @@ class InputPadder:
         return K
 
     def pad(self, *tensors, K=None):
+        """Like the reference (core/utils/utils.py:19-28): the bare list of padded tensors when `K` is None
+        (`image1, image2 = padder.pad(image1, image2)`, evaluate_stereo.py:239), `(list, shifted K)` otherwise."""
         for t in tensors:
             if t.ndim != 4:
                 raise ValueError("InputPadder.pad expects [N,C,H,W] tensors")
         padded = [F.pad(t, [self.left, self.right, self.top, self.bottom], mode="replicate") for t in tensors]
-        return padded, (None if K is None else self._shift(K, +1))
+        return padded if K is None else (padded, self._shift(K, +1))
 
     def unpad(self, x, K=None):
         if x.ndim != 4:

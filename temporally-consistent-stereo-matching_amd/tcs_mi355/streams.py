@@ -5,9 +5,10 @@ motion encoder and the coarse GRUs; the two stems of the gradient predictor; its
 candidate branch of DispRefine).  Each of those kernels fills only part of the 256 CUs, so running the chains
 side by side raises occupancy.  Under HIP-graph capture the fork/join becomes parallel branches of the graph.
 
-OFF by default: on ROCm 7.2 `hipStreamEndCapture` segfaults on the forked capture of a whole frame (≈1,800 nodes),
-so the default (graph replay) path stays single-stream.  Enable with TCS_MI355_STREAMS=1 together with eager
-launches (TCS_MI355_GRAPH=0) to experiment.
+OFF by default (+1 % measured).  Enable with TCS_MI355_STREAMS=1.  On ROCm 7.2 `hipStreamEndCapture` segfaults when a
+SIDE branch of a captured fork forks again (tools/repro_fork_capture.py), so while a capture is in progress a nested
+fork runs its branches serially on the stream it is on instead of forking; top-level forks are captured as parallel
+graph branches.
 """
 from __future__ import annotations
 
@@ -37,6 +38,8 @@ def fork_join(fns: Sequence[Callable[[], object]], site: str = "") -> list:
     if not ENABLED or len(fns) <= 1 or not torch.cuda.is_available() or ("all" not in SITES and site not in SITES):
         return [f() for f in fns]
     global _DEPTH
+    if _DEPTH > 0 and torch.cuda.is_current_stream_capturing():
+        return [f() for f in fns]          # nested fork under capture: serial (ROCm 7.2 hipStreamEndCapture crash, see above)
     cur = torch.cuda.current_stream()
     sides = _side_streams(cur.device, _DEPTH, len(fns) - 1)
     results = [None] * len(fns)

@@ -320,7 +320,7 @@ def test_e2e_c1_golden(dev, e2e_golden, model):
     from tcs_mi355.harness import InputPadder
     pr = synth.make_pair(1)
     i1, i2 = D(pr.image1, dev)[None], D(pr.image2, dev)[None]
-    (p1, p2), _ = InputPadder(i1.shape, divis_by=32).pad(i1, i2)
+    p1, p2 = InputPadder(i1.shape, divis_by=32).pad(i1, i2)
     out = model(p1, p2, iters=8, test_mode=True)
     assert tuple(out["flow"].shape) == (1, 1, 256, 320)
     assert epe(out["flow_q"], e2e_golden["c1_flow_q"]) <= 1e-4
@@ -350,6 +350,23 @@ def test_e2e_c2_golden(dev, e2e_golden, model):
     fr = synth.make_sequence(2000, n_frames=1).frames[0]
     out = model(D(fr.image1, dev)[None], D(fr.image2, dev)[None], iters=32, test_mode=True)
     assert epe(out["flow_q"], e2e_golden["c2_flow_q"]) <= 1e-3
+
+
+def test_e2e_c2_temporal_32iters_vs_oracle(dev, oracle, synth_weights, model):
+    """BASELINE config 2 beyond frame 0: the first TEMPORAL frame (warp branch) at 640x480 and 32 iterations against the
+    CPU oracle on identical inputs (what bench.py reports as epe_vs_oracle_first_frames).  1e-3 EPE (north_star)."""
+    from tcs_mi355 import synth
+    from tcs_mi355.harness import run_sequence
+    seq = synth.make_sequence(2000, n_frames=2, height=480, width=640, max_disp=192.0)
+    got, ref = [], []
+    run_sequence(model, seq, iters=32, device=dev, collect=got)
+    torch.set_num_threads(min(16, len(__import__("os").sched_getaffinity(0))))
+    run_sequence(lambda a, b, **kw: oracle.tc_stereo_forward(synth_weights, a, b, iters=kw["iters"], params=kw["params"]), seq,
+                 iters=32, device=torch.device("cpu"), collect=ref)
+    for t in range(2):
+        e = epe(got[t], ref[t])
+        print(f"C2 frame {t} (32 iters): EPE vs oracle {e:.2e}")
+        assert e <= 1e-3, (t, e)
 
 
 def test_e2e_kitti_shape_vs_oracle(dev, oracle, synth_weights, model):
@@ -459,11 +476,43 @@ def test_graph_replay_matches_eager(dev, model):
     graphed, again = [], []
     run_sequence(model, seq, iters=3, device=dev, collect=graphed)      # captures
     run_sequence(model, seq, iters=3, device=dev, collect=again)        # pure replay
-    assert model._graphs is not None and all(v is not None for v in model._graphs.cache.values()), "capture fell back to eager"
+    assert model._graphs is not None and model._graphs.fell_back == 0 and all(v is not None for v in model._graphs.cache.values()), \
+        "capture fell back to eager"
     for t in range(3):
         # not bit-identical: MIOpen may choose another algorithm for the extractor convs under capture, and the
         # splat's float atomics commit in a different order from run to run
         assert epe(graphed[t], eager[t]) <= 1e-5 and epe(again[t], eager[t]) <= 1e-5, t
+
+
+def test_graph_recaptures_when_weights_change(dev, synth_weights):
+    """A captured frame graph holds the packed weight images of its capture: after load_state_dict (or any in-place
+    parameter write) the cache must be dropped, or replays would mix old packed weights with new biases."""
+    from argparse import Namespace
+    from core.tc_stereo import TCStereo
+    from tcs_mi355 import synth
+    args = Namespace(hidden_dims=[128] * 3, shared_backbone=True, corr_levels=4, corr_radius=4, n_downsample=2,
+                     context_norm="none", slow_fast_gru=False, n_gru_layers=3, mixed_precision=False, init_thres=0.5)
+    m = TCStereo(args)
+    m.load_state_dict(synth_weights, strict=True)
+    m = m.to(dev).eval()
+    pr = synth.make_pair(3, height=96, width=128, max_disp=24.0)
+    i1, i2 = D(pr.image1, dev)[None], D(pr.image2, dev)[None]
+    m.use_hip_graph = True
+    first = m(i1, i2, iters=2, test_mode=True)["flow"].clone()
+    other = {k: (v * 1.25 if k.endswith("flow_head.conv1.weight") or k.endswith("gru08.convq.weight") else v) for k, v in synth_weights.items()}
+    m.load_state_dict(other, strict=True)
+    graphed = m(i1, i2, iters=2, test_mode=True)["flow"].clone()
+    assert m._graphs.fell_back == 0 and m._graphs.captures == 2
+    m.use_hip_graph = False
+    eager = m(i1, i2, iters=2, test_mode=True)["flow"]
+    assert epe(graphed, eager) <= 1e-5
+    assert epe(graphed, first) > 1e-4, "the changed weights must change the output"
+    with torch.no_grad():
+        m.update_block.flow_head.conv1.weight.mul_(0.5)          # in-place write: _version changes
+    m.use_hip_graph = True
+    again = m(i1, i2, iters=2, test_mode=True)["flow"].clone()
+    m.use_hip_graph = False
+    assert epe(again, m(i1, i2, iters=2, test_mode=True)["flow"]) <= 1e-5 and m._graphs.captures == 3
 
 
 def test_f16x3_split_is_fp32_grade(dev):

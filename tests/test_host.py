@@ -114,6 +114,11 @@ def test_input_padder_and_metrics():
     assert torch.equal(y[..., 0, 3:1245], x[..., 0, :])              # replicate
     z, K3 = p.unpad(y, K=K2)
     assert torch.equal(z, x) and torch.allclose(K3, K)
+    # K=None: the bare list, as the reference returns it (core/utils/utils.py:19-28; evaluate_stereo.py:239 unpacks it)
+    y1, y2 = p.pad(x, x + 1)
+    assert torch.equal(y1, y) and torch.equal(y2, y + 1)
+    only = p.pad(x)
+    assert isinstance(only, list) and len(only) == 1 and torch.equal(only[0], y)
     q = InputPadder((1, 3, 240, 320), divis_by=32)
     assert (q.top, q.bottom, q.left, q.right) == (8, 8, 0, 0)        # config 1: 240 -> 256 rows
     k = InputPadder((1, 3, 375, 1242), mode="kitti", divis_by=32)
@@ -181,6 +186,21 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
     assert res["mine"] == [0, 2, 4] and res["n"] == 2 and res["slow"] == 2.0
     assert res["red"]["frames"] == 5
     assert res["red"]["epe"] == pytest.approx(np.mean([0, 1, 2, 3, 4]))
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` outside torchrun starts 2 ranks itself (BASELINE configs[3] is driven this way at N = 8);
+    --dry-run swaps the model for a sleep so the launcher, rendezvous, barrier and statistics gather run on CPU over gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--dry-run"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["dist_world_size"] == 2 and line["ranks_frames"] == [3, 3] and line["dist_backend"] == "gloo"
+    # a torchrun environment whose WORLD_SIZE disagrees with --gpus must fail loudly instead of printing n_gpus: 1
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
 
 
 def test_formats_known_answers(tmp_path):

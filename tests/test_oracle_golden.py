@@ -149,7 +149,7 @@ def test_e2e_c1_first_frame(oracle, e2e_golden, synth_weights):
     assert _sha(pr.image1, pr.image2) == bytes(e2e_golden["c1_input_sha"]).decode()
     i1, i2 = T(pr.image1)[None], T(pr.image2)[None]
     padder = InputPadder(i1.shape, divis_by=32)
-    (p1, p2), _ = padder.pad(i1, i2)
+    p1, p2 = padder.pad(i1, i2)
     out = oracle.tc_stereo_forward(synth_weights, p1, p2, iters=8)
     assert epe(out["flow_q"], e2e_golden["c1_flow_q"]) <= 1e-4
     assert epe(out["flow"], e2e_golden["c1_flow"]) <= 1e-4
