@@ -208,6 +208,38 @@ def cpu_baseline(W, seq, gpu_preds, n_frames=3):
                       f"oracle/tcs_oracle.py on torch CPU fp32, {torch.get_num_threads()} threads"}, epes
 
 
+def real_data_leg(a, dev):
+    """BASELINE configs[2] (TartanAir abandonedfactory/Easy/P000, 480x640, pretrained weights, 32 iters): EPE / D1 and
+    pairs/s through the evaluation harness.  Neither the dataset nor the checkpoint ships with the repository (the
+    reference links them externally, README.md:36-82): when either is missing the leg is skipped and says why."""
+    from tcs_mi355 import harness
+    if not os.path.exists(a.ckpt):
+        return {"status": "skipped", "reason": f"checkpoint {a.ckpt!r} not found (no pretrained weights offline)"}
+    seq = harness.load_tartanair_sequence(a.tartanair, max_frames=30)
+    if seq is None:
+        return {"status": "skipped", "reason": f"TartanAir folder: {harness.load_tartanair_sequence.why}"}
+    try:
+        from argparse import Namespace
+
+        from core.tc_stereo import TCStereo
+        args = Namespace(hidden_dims=[128] * 3, shared_backbone=True, corr_levels=4, corr_radius=4, n_downsample=2,
+                         context_norm="none", slow_fast_gru=False, n_gru_layers=3, mixed_precision=False, init_thres=0.5)
+        model = TCStereo(args)
+        n = harness.load_checkpoint(model, a.ckpt)
+        model = model.to(dev).eval()
+        harness.run_sequence(model, type(seq)(seq.frames[:2], seq.K, seq.baseline), iters=ITERS, device=dev)      # captures
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        stats = harness.run_sequence(model, seq, iters=ITERS, device=dev)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        red = harness.reduce_stats([stats.vector()])
+        return {"status": "ran", "frames": len(seq.frames), "tensors_loaded": n, "pairs_per_s_incl_host_io": round(len(seq.frames) / dt, 3),
+                "epe": round(red["epe"], 4), "d1": round(red["d1"], 3), "d3": round(red["d3"], 3)}
+    except Exception as e:
+        return {"status": "failed", "reason": f"{type(e).__name__}: {e}"}
+
+
 def spawn_ranks(a, argv):
     """`python bench.py --gpus N` outside torchrun: start N fresh rank processes (one per GPU, RCCL over xGMI) BEFORE this
     process has made any GPU call, relay rank 0's JSON line, exit with the worst return code.  The parent never touches
@@ -260,6 +292,11 @@ def main():
                     help="frame size other than BASELINE configs[1]'s 480x640, e.g. 375x1242 for configs[4] (KITTI raw latency)")
     ap.add_argument("--batched-leg", type=int, default=4,
                     help="after the timed run, also time this many sequences per launch (reported under batched_leg; 0/1 = skip)")
+    ap.add_argument("--tartanair", default=os.environ.get("TCS_TARTANAIR_SEQ", "datasets/TartanAir/abandonedfactory/Easy/P000"),
+                    help="BASELINE configs[2]: a TartanAir trajectory folder (image_left/, image_right/, depth_left/, pose_left.txt); "
+                         "skipped with a logged reason when absent")
+    ap.add_argument("--ckpt", default=os.environ.get("TCS_CKPT", "checkpoints/tartanair.pth"),
+                    help="reference checkpoint (.pth with a 'model' state dict) for the TartanAir leg; weights-only load")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher rehearsal without a GPU: ranks, rendezvous, barrier and the statistics gather only (tests)")
     a = ap.parse_args()
@@ -388,6 +425,11 @@ def main():
         ops.LOOKUP_PROBE = None
 
 
+    # BASELINE configs[2]: real TartanAir frames + the reference's pretrained weights, only when both are on the box
+    real = None
+    if rank == 0 and world == 1:
+        real = real_data_leg(a, dev)
+
     if rank == 0:
         line = {
             "metric": f"stereo-pairs/sec at {WIDTH}x{HEIGHT} D=192, 32 GRU iters", "value": round(value, 4), "unit": "stereo-pairs/s",
@@ -400,6 +442,7 @@ def main():
                        "frames_per_rank": a.steps * S, "seqs_per_gpu": S, "weights": "key-seeded synthetic (tcs_mi355.weights)",
                        "launch": "eager" if a.eager else "hip-graph replay"},
             "roofline": roof, "cpu_baseline": cpu, "epe_vs_oracle_first_frames": epe_vs_oracle, "batched_leg": batched,
+            "tartanair_leg": real,
             "ranks_frames": [int(v[0]) for v in vecs],
             "dist_world_size": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
             "dist_backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,

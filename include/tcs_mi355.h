@@ -263,6 +263,62 @@ int tcs_conv3x3_cout1(const float* x, const float* w_oihw, const float* bias, in
  * BasicMotionEncoder / FlowHead / the stride-1 convs of DispRefine and DispGradPredictor (core/update.py). */
 int tcs_conv2d(const tcs_conv_desc* desc, tcs_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Pre-split activations ("S16" tensors): the refinement loop's internal activation format.
+ *
+ * The convolutions contract fp16 hi/lo halves of every fp32 operand (TCS_MATH_F16X3).  Inside the refinement loop
+ * (core/tc_stereo.py:176-210, core/update.py) the PRODUCER of an activation splits it once and stores it in operand
+ * form, so that the consuming convolution stages it with plain 16-byte copies (LDS-DMA) instead of converting it again
+ * for every output tile:
+ *
+ *     logical [B][C][H][W] fp32   ->   _Float16 [B][G][2][H+2][W+2][8]
+ *         G = 2*ceil(C/16) channel groups of 8, [2] = {hi, lo} with x = hi + lo (+ <= 2^-22 |x|, |x| <= 65504),
+ *         a one-pixel ZERO border (the 'same' padding of a 3x3 convolution), zero padding channels.
+ *
+ * The caller allocates the buffer ZERO-FILLED once (tcs_s16_bytes); producers only ever write interior pixels of real
+ * channel groups, so the border stays zero for the buffer's lifetime.  fp32 NCHW remains the format of every reference-facing
+ * entry point above; tcs_s16_from_f32 / tcs_s16_to_f32 convert at the loop's boundary.
+ * ------------------------------------------------------------------------------------------------------------------- */
+size_t tcs_s16_bytes(int B, int C, int H, int W);
+/* x [B,C,H,W] fp32 -> groups [group_offset, group_offset + 2*ceil(C/16)) of an S16 tensor with groups_total groups */
+int tcs_s16_from_f32(const float* x, int B, int C, int H, int W, void* s16, int groups_total, int group_offset, tcs_stream_t stream);
+/* channels [8*group_offset, 8*group_offset + C) of an S16 tensor -> out [B,C,H,W] fp32 (hi + lo) */
+int tcs_s16_to_f32(const void* s16, int B, int C, int H, int W, int groups_total, int group_offset, float* out, tcs_stream_t stream);
+
+typedef struct tcs_conv_s16_desc {
+    /* virtual concatenation of up to 4 S16 sources along channels (torch.cat of update.py:79-80); every source but the
+     * last must carry a multiple of 16 channels */
+    const void* src[TCS_MAX_SRC];
+    int src_ch[TCS_MAX_SRC];        /* logical channels per source */
+    int src_groups[TCS_MAX_SRC];    /* groups allocated per source tensor */
+    int n_src;
+    const float* weight;     /* tcs_pack_conv_weight_f16x3 / tcs_pack_deconv4x4s2_f16x3 of the [Cout, Cin, k, k] weight */
+    const float* bias;       /* [Cout] or NULL */
+    int B, H, W;             /* INPUT grid */
+    int Cin, Cout, ksize;    /* ksize in {1,3} */
+    int stride;              /* 1, or 2 (3x3 pad 1, LINEAR): output (H-1)/2+1 x (W-1)/2+1 */
+    int epilogue;            /* TCS_EPI_* as for tcs_conv2d */
+    int act;
+    float post_scale;
+    float weight_unscale;
+    const float* addend;     /* fp32 NCHW: LINEAR addend [B,Cout,Ho,Wo]; GRU_ZR cz / GRU_Q cq [B,hidden,H,W] (nullable) */
+    const float* addend2;    /* GRU_ZR: cr */
+    const void* h;           /* GRU: hidden state, S16 with h_groups groups */
+    int h_groups;
+    const float* z;          /* GRU_Q: update gate, fp32 [B,hidden,H,W] */
+    int blend_keep_z;
+    void* out16;             /* S16 output (LINEAR: act(.)*post_scale; DECONV2X: [C/4 channels, 2H, 2W]; GRU_ZR: r*h;
+                                GRU_Q: new h, may alias `h`), written at group offset out16_group_offset; nullable for LINEAR */
+    int out16_groups, out16_group_offset;
+    float* out32;            /* fp32 NCHW output: LINEAR (nullable; [B,out_ctot,Ho,Wo] at channel out_coff); GRU_ZR: z (required);
+                                GRU_Q: optional fp32 copy of the new h */
+    int out_ctot, out_coff;
+    int tile_cfg;            /* 0 = choose by grid size; otherwise MT*1000 + ROWS*100 + KSTEPS*10 + NSTAGE (benchmarks, tests) */
+} tcs_conv_s16_desc;
+
+/* nn.Conv2d / ConvGRU step on S16 activations (core/update.py:16-17,26-36,57-68,77-87,103-111,198-214,291-305) */
+int tcs_conv2d_s16(const tcs_conv_s16_desc* desc, tcs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,10 +76,9 @@ class ResidualBlock(nn.Module):
 
 
 def _hip_trunk() -> bool:
-    """TCS_MI355_EXTRACTOR=torch keeps the whole extractor on PyTorch-ROCm; stride-2 needs the fp16-split kernel."""
+    """TCS_MI355_EXTRACTOR=torch keeps the whole extractor on PyTorch-ROCm (used by tests as the comparison leg)."""
     import os
-    from core.update import hip_ok_stride2
-    return os.environ.get("TCS_MI355_EXTRACTOR", "hip") != "torch" and hip_ok_stride2()
+    return os.environ.get("TCS_MI355_EXTRACTOR", "hip") != "torch"
 
 
 def hip_head(f, x):

@@ -1,0 +1,613 @@
+// Convolutions on PRE-SPLIT activations ("S16" tensors) for gfx950: the refinement loop's conv kernel.
+//
+// The fp16-split contraction of tcs_conv_f16.hip (x = hi + lo, three v_mfma_f32_32x32x16_f16 per product, fp32
+// accumulate, error ~2^-21) spent most of its issue slots turning fp32 NCHW activations into LDS operand images: each
+// element was loaded as a dword, clamped, converted twice and stored to LDS ~6 times (4 cout tiles x 1.6 halo overlap) —
+// 8.5 non-MFMA instructions per MFMA (profiles/r01_conv_gru08zr_pmc.txt).  Here the PRODUCER splits once, in its
+// epilogue, and activations live in HBM already in operand form:
+//
+//   S16 tensor of a logical [B][C][H][W] fp32 tensor:   _Float16 [B][G][2][H+2][W+2][8]
+//       G = ceil(C/8) rounded up to even, [2] = {hi, lo} planes, a 16-byte unit = 8 consecutive channels of one pixel,
+//       one-pixel ZERO border (written once at allocation, never by a producer), zero padding channels.
+//       Same 4 bytes per element as fp32.
+//
+// A unit is exactly one lane's B-operand fragment of v_mfma_f32_32x32x16_f16 (k = 8 channels of lane-half h), so staging
+// is a straight copy: LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPR round trip, no VALU).  The
+// zero border replaces every bounds test of a 3x3 'same' convolution; tiles that overhang the right / bottom edge read
+// clamped (valid, finite) positions and never store those pixels (MFMA columns are independent).
+//
+// Tiling: block = ROWS waves, wave = one output row of 32 pixels x 32*MT output channels (D: pixel on the lane).
+// K loop over stages of KSTEPS 16-channel k-steps x all taps; NSTAGE LDS buffers:
+//     wait own DMA pieces of stage s (counted vmcnt) -> s_barrier -> issue DMA of stage s+NSTAGE-1 -> MFMAs of stage s
+// i.e. ONE barrier per stage and NSTAGE-1 stages of prefetch in flight across it.  Operand fetches are inline-asm
+// ds_read_b128 with counted lgkmcnt (hipcc would put vmcnt(0) in front of every LDS read that may alias a DMA).
+// Weights: the f16x3 packed image of tcs_pack_conv_weight_f16x3, unchanged.
+//
+// Epilogues (bias, fp32 addends, activation, GRU gate arithmetic, pixel shuffle of the transposed convs) run on the
+// accumulators and write S16 (8-byte stores: 4 channels of one pixel, hi or lo) and/or fp32 NCHW.
+#include "tcs_conv_common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+struct S16Args {
+    const _Float16* src[TCS_MAX_SRC];   // S16 sources (virtual concat along channels)
+    int src_groups[TCS_MAX_SRC];        // groups allocated per source tensor (even)
+    int src_kend[TCS_MAX_SRC];          // cumulative k-steps after each source (unused sources: INT_MAX)
+    const float* w;                     // f16x3 packed weights
+    const float* bias;
+    int B, H, W;                        // output grid
+    int Hin, Win;                       // input grid (all sources)
+    int nk;                             // total 16-channel k-steps
+    int Cout, nct32;                    // output channels, packed 32-channel tiles
+    int act;
+    float post_scale, w_unscale;
+    const float* add1;                  // fp32 NCHW addends ([B][Cout or hidden][H][W])
+    const float* add2;
+    const _Float16* h;                  // GRU: hidden state, S16 [B][h_groups][2][H+2][W+2][8]
+    int h_groups;
+    const float* z;                     // GRU_Q: update gate, fp32 NCHW
+    int keep_z, hidden;
+    _Float16* out16;                    // S16 output (nullable) written at group offset out16_goff
+    int out16_groups, out16_goff;
+    float* out32;                       // fp32 NCHW output (nullable): LINEAR out / GRU_ZR z
+    int out_ctot, out_coff;
+    int npx, nct;
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// S16 element access helpers (epilogues, conversion kernels)
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split4(const float* v, half4& hi, half4& lo) {
+    // x = hi + lo (+ <= 2^-22 |x|); saturates at +-65504 (a NaN stays a NaN: fmed3 returns it... see s16_sat_flag)
+#pragma unroll
+    for (int j = 0; j < 4; j += 2) {
+        float2_t x;
+        x[0] = __builtin_amdgcn_fmed3f(v[j], -65504.f, 65504.f);
+        x[1] = __builtin_amdgcn_fmed3f(v[j + 1], -65504.f, 65504.f);
+        const half2_t h2 = __builtin_convertvector(x, half2_t);
+        const float2_t back = __builtin_convertvector(h2, float2_t);
+        const half2_t l2 = __builtin_convertvector(x - back, half2_t);
+        hi[j] = h2[0]; hi[j + 1] = h2[1]; lo[j] = l2[0]; lo[j + 1] = l2[1];
+    }
+}
+
+// offset (in halves) of unit (b, g, hl, y, x) of an S16 tensor with G groups on an H x W grid (interior coordinates)
+__device__ __forceinline__ size_t s16_unit(int b, int G, int g, int hl, int Hp, int Wp, int y, int x) {
+    return ((((size_t)b * G + g) * 2 + hl) * Hp + (y + 1)) * (size_t)Wp * 8 + (size_t)(x + 1) * 8;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// epilogue of one 32(cout) x 32(pixel) accumulator tile; lane = pixel, register r -> channel co0 + (r&3) + 8*(r>>2)
+// (co0 already includes the lane half's +4).  S16 stores: the 4 registers 4q..4q+3 are 4 consecutive channels of group
+// (co0>>3)+q -> one 8-byte store per {hi, lo}.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int EPI>
+__device__ __forceinline__ void s16_epilogue_tile(const S16Args& a, int b, int co0, int py, int px, const f32x16& acc) {
+    const int H = a.H, W = a.W;
+    const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
+    const int Hp = H + 2, Wp = W + 2;
+    int cc[16];
+    bool ok[16];
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (r & 3) + 8 * (r >> 2);
+        ok[r] = co < a.Cout;
+        cc[r] = min(co, a.Cout - 1);
+        v[r] = acc[r] * a.w_unscale;
+    }
+    if (a.bias) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += a.bias[cc[r]];
+    }
+    const int sub4 = co0 & 4;                        // this lane half's 4-channel slot inside a group
+    if (EPI == TCS_EPI_LINEAR) {
+        if (a.add1) {
+            float t[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = a.add1[((size_t)b * a.Cout + cc[r]) * HW + pix];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += t[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = ok[r] ? apply_act(v[r], a.act) * a.post_scale : 0.f;
+        if (a.out32) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (ok[r]) a.out32[((size_t)b * a.out_ctot + a.out_coff + cc[r]) * HW + pix] = v[r];
+        }
+        if (a.out16) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int g = (co0 >> 3) + q;
+                if (g * 8 < ((a.Cout + 7) & ~7)) {                   // groups that hold real channels
+                    half4 hi, lo;
+                    split4(&v[4 * q], hi, lo);
+                    _Float16* o = a.out16 + s16_unit(b, a.out16_groups, a.out16_goff + g, 0, Hp, Wp, py, px) + sub4;
+                    *reinterpret_cast<half4*>(o) = hi;
+                    *reinterpret_cast<half4*>(o + (size_t)Hp * Wp * 8) = lo;
+                }
+            }
+        }
+    } else if (EPI == TCS_EPI_DECONV2X) {
+        // ConvTranspose2d(4, 2, 1) as a 3x3 conv with 4*C outputs (one group of C per output parity), pixel-shuffled:
+        // channel par*C + c of pixel (i,j) -> out[c][2i + (par>>1)][2j + (par&1)]; C is a multiple of 8
+        const int C = a.hidden, Ho = 2 * H, Wo = 2 * W;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cbase = co0 + 8 * q;                            // 4 consecutive channels, same parity group
+            if (cbase < a.Cout) {
+                const int par = cbase / C, c = cbase - par * C;
+                float t[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] = apply_act(v[4 * q + j], a.act);
+                half4 hi, lo;
+                split4(t, hi, lo);
+                _Float16* o = a.out16 + s16_unit(b, a.out16_groups, a.out16_goff + (c >> 3), 0, Ho + 2, Wo + 2, 2 * py + (par >> 1),
+                                                  2 * px + (par & 1)) + (c & 4);
+                *reinterpret_cast<half4*>(o) = hi;
+                *reinterpret_cast<half4*>(o + (size_t)(Ho + 2) * (Wo + 2) * 8) = lo;
+            }
+        }
+    } else {
+        // GRU epilogues.  ZR: tile channels < hidden are z (-> fp32 out32), the others r (-> r*h, S16 out16).
+        // Q: q = tanh(. + cq), h' = blend(z, h, q) -> S16 out16 (may alias a.h: same positions read then written).
+        const bool is_r = (EPI == TCS_EPI_GRU_ZR) && (co0 >= a.hidden);           // tile-uniform (hidden % 32 == 0)
+        const int chb = is_r ? co0 - a.hidden : co0;                               // channel within [0, hidden)
+        float hh[16], ad[16], zz[16];
+        size_t o32[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o32[r] = ((size_t)b * a.hidden + chb + (r & 3) + 8 * (r >> 2)) * HW + pix;
+        const float* addp = (EPI == TCS_EPI_GRU_ZR && is_r) ? a.add2 : a.add1;
+        if (addp) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ad[r] = addp[o32[r]];
+        }
+        const bool need_h = (EPI == TCS_EPI_GRU_Q) || is_r;
+        if (need_h) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const _Float16* hp = a.h + s16_unit(b, a.h_groups, (chb >> 3) + q, 0, Hp, Wp, py, px) + sub4;
+                const half4 hi = *reinterpret_cast<const half4*>(hp);
+                const half4 lo = *reinterpret_cast<const half4*>(hp + (size_t)Hp * Wp * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hh[4 * q + j] = (float)hi[j] + (float)lo[j];
+            }
+        }
+        if (EPI == TCS_EPI_GRU_Q) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zz[r] = a.z[o32[r]];
+        }
+        float res[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pre = v[r] + (addp ? ad[r] : 0.f);
+            if (EPI == TCS_EPI_GRU_ZR) {
+                const float g = sigmoidf_(pre);
+                res[r] = is_r ? g * hh[r] : g;
+            } else {
+                const float qv = tanhf(pre);
+                res[r] = a.keep_z ? zz[r] * hh[r] + (1.f - zz[r]) * qv : (1.f - zz[r]) * hh[r] + zz[r] * qv;
+            }
+        }
+        if (EPI == TCS_EPI_GRU_ZR && !is_r) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a.out32[o32[r]] = res[r];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                half4 hi, lo;
+                split4(&res[4 * q], hi, lo);
+                _Float16* o = a.out16 + s16_unit(b, a.out16_groups, a.out16_goff + (chb >> 3) + q, 0, Hp, Wp, py, px) + sub4;
+                *reinterpret_cast<half4*>(o) = hi;
+                *reinterpret_cast<half4*>(o + (size_t)Hp * Wp * 8) = lo;
+            }
+            if (EPI == TCS_EPI_GRU_Q && a.out32) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a.out32[o32[r]] = res[r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS-DMA of one 1 KiB piece: 64 lanes x 16 B from (wave-uniform base + per-lane byte offset) to LDS byte address `dst`
+// (wave-uniform) + lane * 16.  M0 is saved/restored inside the statement (it is compiler-reserved).
+#define S16_DMA(VOFF, DST, BASE)                                                                                      \
+    {                                                                                                                 \
+        unsigned keep_;                                                                                               \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"  \
+                     : "=&s"(keep_) : "v"(VOFF), "s"(DST), "s"(BASE) : "memory");                                    \
+    }
+
+// RS = 1 ("row split", 3x3 stride 1): a stage holds ONE filter row (3 taps) of KSTEPS k-steps and the ROWS x 34 input rows it
+// reads, i.e. the 3x3 convolution runs as three 1x3 convolutions on vertically shifted inputs.  Activations are fetched
+// 2x instead of 1.5x (L2-resident), but a stage shrinks from 49 to 21 KiB (MT = 2), so that two or three workgroups fit a CU
+// with the 64-channel tile: the 32-channel tile (4 LDS reads per 3 MFMAs) is LDS-bandwidth bound, and one workgroup per CU
+// cannot hide its own DMA latency and barriers.
+// a wave-uniform pointer the compiler may have parked in VGPRs (SGPR pressure): back to an SGPR pair for the "s" operand
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+
+template <int KS, int MT, int ROWS, int KSTEPS, int NSTAGE, int STRIDE, int EPI, int RS = 0>
+__global__ __launch_bounds__(64 * ROWS) void k_conv_s16(S16Args a) {
+    static_assert(!RS || (KS == 3 && STRIDE == 1), "row split is for 3x3 stride-1 convolutions");
+    constexpr int HALO = KS / 2, TAPS = KS * KS, TS = RS ? KS : TAPS;                       // TS: taps per stage
+    constexpr int IH = RS ? ROWS : STRIDE * ROWS + KS - STRIDE, IW = STRIDE * 32 + KS - STRIDE, IN_CH = IH * IW;
+    constexpr int IN_UNITS = KSTEPS * 4 * IN_CH;                    // sub-tiles [kstep][lane half][hi|lo][IH][IW]
+    constexpr int NPI = (IN_UNITS + 63) / 64, NPW = KSTEPS * TS * MT * 2, NP = NPI + NPW;
+    constexpr int PPW = (NP + ROWS - 1) / ROWS;                     // DMA pieces per wave per stage
+    constexpr int STAGE_BYTES = NP * 1024, W_OFF = NPI * 1024;
+    constexpr int NSTEP = KSTEPS * TS, R = 2 + 2 * MT;              // operand reads per (k-step, tap)
+    static_assert(R <= 15, "lgkmcnt field");
+    static_assert(STAGE_BYTES <= 65536, "ds_read immediate offsets are 16 bits");
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bid = blockIdx.x;
+    const int ct = bid % a.nct, patch = bid / a.nct;
+    const int b = blockIdx.y;
+    const int y0 = (patch / a.npx) * ROWS, x0 = (patch % a.npx) * 32;
+    const int Hp = a.Hin + 2, Wp = a.Win + 2;
+    const unsigned plane = (unsigned)(Hp * Wp);                     // units per {hi|lo} plane
+    const unsigned lds_base = __builtin_amdgcn_groupstaticsize();   // no static __shared__ in this kernel
+
+    // ---- DMA plan: piece p = wave + j*ROWS of every stage; per-lane source offset fixed over the K loop ------------------
+    unsigned voff[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int p = min(wave + j * ROWS, NP - 1);                 // surplus slots repeat the last piece (same data, same place)
+        if (p < NPI) {
+            const int u = min(p * 64 + lane, IN_UNITS - 1);
+            const int sub = u / IN_CH, pos = u - sub * IN_CH;
+            const int row = pos / IW, col = pos - row * IW;
+            // padded coordinates; RS adds the filter row (0..KS-1) through the stage's base pointer
+            const int gy = min(STRIDE * y0 + row - HALO + 1, Hp - 1 - (RS ? KS - 1 : 0)), gx = min(STRIDE * x0 + col - HALO + 1, Wp - 1);
+            voff[j] = ((unsigned)sub * plane + (unsigned)(gy * Wp + gx)) * 16u;
+        } else {
+            const int uw = (p - NPI) * 64 + lane;
+            const int slot = uw & 63, hl = (uw >> 6) & 1, m = (uw >> 7) % MT, kt = uw / (128 * MT);
+            const int gt = (kt / TS) * TAPS + kt % TS;              // global tap index relative to the stage's first one
+            voff[j] = ((unsigned)(gt * a.nct32 + m) * 128u + hl * 64u + slot) * 16u;
+        }
+    }
+    // sources (batch-adjusted) and k-step boundaries in scalar registers before the loop: no s_load inside it
+    const size_t plane_bytes = (size_t)plane * 16;
+    const char* sb0 = reinterpret_cast<const char*>(a.src[0]) + (size_t)b * a.src_groups[0] * 2 * plane_bytes;
+    const char* sb1 = reinterpret_cast<const char*>(a.src[1]) + (size_t)b * a.src_groups[1] * 2 * plane_bytes;
+    const char* sb2 = reinterpret_cast<const char*>(a.src[2]) + (size_t)b * a.src_groups[2] * 2 * plane_bytes;
+    const char* sb3 = reinterpret_cast<const char*>(a.src[3]) + (size_t)b * a.src_groups[3] * 2 * plane_bytes;
+    const int ke0 = a.src_kend[0], ke1 = a.src_kend[1], ke2 = a.src_kend[2];
+    const char* wbase = reinterpret_cast<const char*>(a.w) + (size_t)ct * MT * 2048;
+    const size_t w_kstep_bytes = (size_t)TAPS * a.nct32 * 2048;
+    const int nstage_total = (a.nk / KSTEPS) * (RS ? KS : 1);
+    const size_t row_bytes = (size_t)Wp * 16, w_row_bytes = (size_t)KS * a.nct32 * 2048;
+
+#define S16_ISSUE(BUF, SIDX)                                                                                          \
+    {                                                                                                                 \
+        const int k0_ = (RS ? (SIDX) / KS : (SIDX)) * KSTEPS, dy_ = RS ? (SIDX) % KS : 0;                             \
+        const bool p1_ = k0_ >= ke0, p2_ = k0_ >= ke1, p3_ = k0_ >= ke2;                                              \
+        const char* sp_ = p3_ ? sb3 : (p2_ ? sb2 : (p1_ ? sb1 : sb0));                                                \
+        const int ks_ = p3_ ? ke2 : (p2_ ? ke1 : (p1_ ? ke0 : 0));                                                    \
+        const char* in_ptr_ = uniform_ptr(sp_ + (size_t)(k0_ - ks_) * 4 * plane_bytes + dy_ * row_bytes);             \
+        const char* w_ptr_ = uniform_ptr(wbase + (size_t)k0_ * w_kstep_bytes + dy_ * w_row_bytes);                    \
+        const unsigned dst0_ = lds_base + (unsigned)(BUF) * STAGE_BYTES;                                              \
+        asm volatile("s_nop 4" ::: "memory");       /* v_readfirstlane-written SGPRs -> VMEM base: wait states */        \
+        _Pragma("unroll") for (int j = 0; j < PPW; ++j) {                                                             \
+            const int p_ = min(wave + j * ROWS, NP - 1);                                                              \
+            const char* base_ = p_ < NPI ? in_ptr_ : w_ptr_;                                                          \
+            S16_DMA(voff[j], dst0_ + (unsigned)p_ * 1024u, base_)                                                     \
+        }                                                                                                             \
+    }
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+
+    // operand fetch addresses inside a stage buffer
+    const unsigned addr_b0 = lds_base + (unsigned)((half * 2 * IN_CH + STRIDE * wave * IW + STRIDE * l31) * 16);
+    const unsigned addr_a0 = lds_base + (unsigned)(W_OFF + lane * 16);
+    struct Frag { half8 b_hi, b_lo, a_hi[MT], a_lo[MT]; };
+#define S16_DSREAD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "i"(OFF) : "memory")
+#define S16_FETCH(F, STEP)                                                                                            \
+    {                                                                                                                 \
+        const int kk_ = (STEP) / TS, t_ = (STEP) % TS, dy_ = RS ? 0 : t_ / KS, dx_ = t_ % KS;  /* constants after unrolling */ \
+        S16_DSREAD(F.b_hi, addr_b, ((kk_ * 4 + 0) * IN_CH + dy_ * IW + dx_) * 16);                                    \
+        S16_DSREAD(F.b_lo, addr_b, ((kk_ * 4 + 1) * IN_CH + dy_ * IW + dx_) * 16);                                    \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                              \
+            S16_DSREAD(F.a_hi[m], addr_a, (((kk_ * TS + t_) * MT + m) * 2 + 0) * 1024);                               \
+            S16_DSREAD(F.a_lo[m], addr_a, (((kk_ * TS + t_) * MT + m) * 2 + 1) * 1024);                               \
+        }                                                                                                             \
+    }
+#define S16_WAIT_LGKM(N) { asm volatile("s_waitcnt lgkmcnt(%0)" :: "i"(N) : "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define S16_MMA(F)                                                                                                    \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                                  \
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_lo[m], F.b_hi, acc[m], 0, 0, 0);                          \
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_hi[m], F.b_lo, acc[m], 0, 0, 0);                          \
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_hi[m], F.b_hi, acc[m], 0, 0, 0);                          \
+    }
+
+    // ---- prologue: NSTAGE-1 stages in flight ---------------------------------------------------------------------------
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < nstage_total) S16_ISSUE(s, s)
+
+    int buf = 0;                                                    // buffer of the stage being multiplied
+    for (int s = 0; s < nstage_total; ++s) {
+        // own pieces of stage s have landed: all but the stages issued after it (each PPW pieces) may still be in flight
+        const int newer = min(nstage_total - 1 - s, NSTAGE - 2);
+        if (NSTAGE >= 3 && newer == NSTAGE - 2) { asm volatile("s_waitcnt vmcnt(%0)" :: "i"((NSTAGE - 2) * PPW) : "memory"); }
+        else if (NSTAGE >= 4 && newer == NSTAGE - 3) { asm volatile("s_waitcnt vmcnt(%0)" :: "i"((NSTAGE >= 4 ? NSTAGE - 3 : 0) * PPW) : "memory"); }
+        else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        __builtin_amdgcn_s_barrier();                               // everyone's pieces landed; everyone is done with stage s-1
+        if (s + NSTAGE - 1 < nstage_total) {
+            int nb = buf + NSTAGE - 1;
+            nb = nb >= NSTAGE ? nb - NSTAGE : nb;
+            S16_ISSUE(nb, s + NSTAGE - 1)
+        }
+        {
+            const unsigned addr_b = addr_b0 + (unsigned)buf * STAGE_BYTES, addr_a = addr_a0 + (unsigned)buf * STAGE_BYTES;
+            Frag f0, f1;
+            S16_FETCH(f0, 0)
+#pragma unroll
+            for (int i = 0; i < NSTEP; i += 2) {
+                if (i + 1 < NSTEP) { S16_FETCH(f1, (i + 1 < NSTEP ? i + 1 : 0)) S16_WAIT_LGKM(R) } else S16_WAIT_LGKM(0)
+                S16_MMA(f0)
+                if (i + 1 < NSTEP) {
+                    if (i + 2 < NSTEP) { S16_FETCH(f0, (i + 2 < NSTEP ? i + 2 : 0)) S16_WAIT_LGKM(R) } else S16_WAIT_LGKM(0)
+                    S16_MMA(f1)
+                }
+            }
+        }
+        buf = buf + 1 == NSTAGE ? 0 : buf + 1;
+    }
+#undef S16_ISSUE
+#undef S16_FETCH
+#undef S16_MMA
+
+    const int px = x0 + l31, py = y0 + wave;
+    if (px >= a.W || py >= a.H) return;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) s16_epilogue_tile<EPI>(a, b, (ct * MT + m) * 32 + 4 * half, py, px, acc[m]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32 NCHW <-> S16
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_s16_from_f32(const float* __restrict__ x, int C, int H, int W, int G, int goff, int Gtot,
+                                                       _Float16* __restrict__ out) {
+    // thread = one unit (b, g, y, x): 8 channels of one pixel; channels >= C are written as zero
+    const int HW = H * W;
+    const size_t n = (size_t)G * HW;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= n) return;
+    const int g = (int)(i / HW), p = (int)(i - (size_t)g * HW);
+    const int y = p / W, xx = p - y * W;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = g * 8 + j;
+        v[j] = c < C ? x[((size_t)b * C + c) * HW + p] : 0.f;
+    }
+    half4 h0, l0, h1, l1;
+    split4(v, h0, l0);
+    split4(v + 4, h1, l1);
+    half8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { hi[j] = h0[j]; hi[j + 4] = h1[j]; lo[j] = l0[j]; lo[j + 4] = l1[j]; }
+    _Float16* o = out + s16_unit(b, Gtot, goff + g, 0, H + 2, W + 2, y, xx);
+    *reinterpret_cast<half8*>(o) = hi;
+    *reinterpret_cast<half8*>(o + (size_t)(H + 2) * (W + 2) * 8) = lo;
+}
+
+__global__ __launch_bounds__(256) void k_s16_to_f32(const _Float16* __restrict__ s, int C, int H, int W, int Gtot, int goff,
+                                                     float* __restrict__ out) {
+    const int HW = H * W, G = (C + 7) / 8;
+    const size_t n = (size_t)G * HW;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= n) return;
+    const int g = (int)(i / HW), p = (int)(i - (size_t)g * HW);
+    const int y = p / W, xx = p - y * W;
+    const _Float16* u = s + s16_unit(b, Gtot, goff + g, 0, H + 2, W + 2, y, xx);
+    const half8 hi = *reinterpret_cast<const half8*>(u);
+    const half8 lo = *reinterpret_cast<const half8*>(u + (size_t)(H + 2) * (W + 2) * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = g * 8 + j;
+        if (c < C) out[((size_t)b * C + c) * HW + p] = (float)hi[j] + (float)lo[j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// launch
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KS, int MT, int ROWS, int KSTEPS, int NSTAGE, int STRIDE, int EPI, int RS = 0>
+static int launch_s16(S16Args& a, hipStream_t s) {
+    constexpr int IH = RS ? ROWS : STRIDE * ROWS + KS - STRIDE, IW = STRIDE * 32 + KS - STRIDE, TS = RS ? KS : KS * KS;
+    constexpr int NPI = (KSTEPS * 4 * IH * IW + 63) / 64, NP = NPI + KSTEPS * TS * MT * 2;
+    constexpr size_t lds = (size_t)NSTAGE * NP * 1024;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    auto kern = k_conv_s16<KS, MT, ROWS, KSTEPS, NSTAGE, STRIDE, EPI, RS>;
+    (void)hipGetLastError();                                        // a stale error of an earlier runtime call is not ours
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return TCS_ELAUNCH;
+    }
+    a.npx = tcs_cdiv(a.W, 32);
+    a.nct = a.nct32 / MT;
+    hipLaunchKernelGGL(kern, dim3(a.npx * tcs_cdiv(a.H, ROWS) * a.nct, a.B), dim3(64 * ROWS), lds, s, a);
+    return tcs_launch_status();
+}
+
+// tile configuration: cfg = RS*10000 + MT*1000 + ROWS*100 + KSTEPS*10 + NSTAGE (0 = heuristic); unknown combinations -> EUNSUPPORTED
+template <int KS, int STRIDE, int EPI>
+static int launch_s16_cfg(S16Args& a, int cfg, hipStream_t s) {
+#define S16_CASE(MT_, ROWS_, KST_, NST_) \
+    case (MT_ * 1000 + ROWS_ * 100 + KST_ * 10 + NST_): return launch_s16<KS, MT_, ROWS_, KST_, NST_, STRIDE, EPI>(a, s);
+#define S16_CASE_RS(MT_, ROWS_, KST_, NST_) \
+    case (10000 + MT_ * 1000 + ROWS_ * 100 + KST_ * 10 + NST_): return launch_s16<KS, MT_, ROWS_, KST_, NST_, STRIDE, EPI, 1>(a, s);
+    if constexpr (KS == 3 && STRIDE == 1) {
+        switch (cfg) {
+            S16_CASE(1, 4, 1, 2) S16_CASE(1, 4, 1, 3) S16_CASE(2, 4, 1, 2) S16_CASE(2, 4, 1, 3)
+            S16_CASE(1, 5, 1, 2) S16_CASE(1, 5, 1, 3) S16_CASE(2, 5, 1, 2) S16_CASE(2, 5, 1, 3)
+            S16_CASE(1, 8, 1, 2) S16_CASE(1, 8, 1, 3) S16_CASE(2, 8, 1, 2)
+            S16_CASE_RS(1, 4, 1, 2) S16_CASE_RS(1, 4, 1, 3) S16_CASE_RS(2, 4, 1, 2) S16_CASE_RS(2, 4, 1, 3) S16_CASE_RS(2, 4, 1, 4)
+            S16_CASE_RS(2, 5, 1, 2) S16_CASE_RS(2, 5, 1, 3) S16_CASE_RS(1, 5, 1, 3)
+            S16_CASE_RS(2, 8, 1, 2) S16_CASE_RS(2, 8, 1, 3) S16_CASE_RS(4, 4, 1, 2) S16_CASE_RS(4, 4, 1, 3)
+            default: return TCS_EUNSUPPORTED;
+        }
+    } else if constexpr (KS == 3) {
+        switch (cfg) {
+            S16_CASE(1, 4, 1, 2)
+            default: return TCS_EUNSUPPORTED;
+        }
+    } else {
+        switch (cfg) {
+            S16_CASE(1, 4, 2, 2) S16_CASE(1, 4, 2, 3) S16_CASE(2, 4, 2, 2) S16_CASE(2, 4, 2, 3)
+            S16_CASE(1, 4, 4, 2) S16_CASE(1, 4, 4, 3) S16_CASE(2, 4, 4, 2) S16_CASE(2, 4, 4, 3)
+            default: return TCS_EUNSUPPORTED;
+        }
+    }
+#undef S16_CASE
+#undef S16_CASE_RS
+}
+
+static int s16_heuristic(const S16Args& a, int ksize, int stride, int min_src_ksteps) {
+    if (ksize == 1) {
+        const int kst = (min_src_ksteps % 4 == 0) ? 4 : 2;
+        const long long blocks2 = (long long)tcs_cdiv(a.W, 32) * tcs_cdiv(a.H, 4) * a.B * (a.nct32 / 2);
+        const int mt = (a.nct32 % 2 == 0 && blocks2 >= 512) ? 2 : 1;
+        return mt * 1000 + 400 + kst * 10 + 3;
+    }
+    if (stride == 2) return 1412;
+    const long long px4 = (long long)tcs_cdiv(a.W, 32) * tcs_cdiv(a.H, 4) * a.B;
+    const int mt = (a.nct32 % 2 == 0 && px4 * (a.nct32 / 2) >= 512) ? 2 : 1;
+    return mt * 1000 + 400 + 10 + 3;
+}
+
+extern "C" {
+
+size_t tcs_s16_bytes(int B, int C, int H, int W) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t G = (size_t)((C + 15) / 16) * 2;
+    return (size_t)B * G * 2 * (H + 2) * (W + 2) * 16;
+}
+
+int tcs_s16_from_f32(const float* x, int B, int C, int H, int W, void* s16, int groups_total, int group_offset, tcs_stream_t stream) {
+    if (!x || !s16 || B <= 0 || B > 65535 || C <= 0 || H <= 0 || W <= 0) return TCS_EINVAL;
+    const int G = ((C + 15) / 16) * 2;
+    if (group_offset < 0 || (group_offset & 1) || group_offset + G > groups_total) return TCS_EINVAL;
+    const size_t n = (size_t)G * H * W;
+    hipLaunchKernelGGL(k_s16_from_f32, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, tcs_stream(stream), x, C, H, W, G, group_offset,
+                       groups_total, reinterpret_cast<_Float16*>(s16));
+    return tcs_launch_status();
+}
+
+int tcs_s16_to_f32(const void* s16, int B, int C, int H, int W, int groups_total, int group_offset, float* out, tcs_stream_t stream) {
+    if (!out || !s16 || B <= 0 || B > 65535 || C <= 0 || H <= 0 || W <= 0) return TCS_EINVAL;
+    const int G = (C + 7) / 8;
+    if (group_offset < 0 || group_offset + G > groups_total) return TCS_EINVAL;
+    const size_t n = (size_t)G * H * W;
+    hipLaunchKernelGGL(k_s16_to_f32, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, tcs_stream(stream),
+                       reinterpret_cast<const _Float16*>(s16), C, H, W, groups_total, group_offset, out);
+    return tcs_launch_status();
+}
+
+int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
+    if (!d || !d->weight || d->n_src < 1 || d->n_src > TCS_MAX_SRC) return TCS_EINVAL;
+    if (d->B <= 0 || d->B > 65535 || d->H <= 0 || d->W <= 0 || d->Cout <= 0) return TCS_EINVAL;
+    if (d->ksize != 1 && d->ksize != 3) return TCS_EUNSUPPORTED;
+    const int stride = d->stride == 2 ? 2 : 1;
+    if (stride == 2 && (d->ksize != 3 || d->epilogue != TCS_EPI_LINEAR)) return TCS_EUNSUPPORTED;
+    S16Args a;
+    int ktot = 0, min_k = 1 << 30, cin = 0;
+    for (int i = 0; i < TCS_MAX_SRC; ++i) {
+        const bool used = i < d->n_src;
+        if (used) {
+            if (!d->src[i] || d->src_ch[i] <= 0 || d->src_groups[i] < ((d->src_ch[i] + 15) / 16) * 2 || (d->src_groups[i] & 1)) return TCS_EINVAL;
+            // every source but the last must fill whole 16-channel k-steps, or the weights' K index would shift
+            if (i + 1 < d->n_src && d->src_ch[i] % 16 != 0) return TCS_EINVAL;
+            const int k = (d->src_ch[i] + 15) / 16;
+            ktot += k;
+            min_k = k < min_k ? k : min_k;
+            cin += d->src_ch[i];
+        }
+        a.src[i] = reinterpret_cast<const _Float16*>(used ? d->src[i] : d->src[0]);
+        a.src_groups[i] = used ? d->src_groups[i] : d->src_groups[0];
+        a.src_kend[i] = used ? ktot : 0x7fffffff;
+    }
+    if (cin != d->Cin) return TCS_EINVAL;
+    a.w = d->weight; a.bias = d->bias;
+    a.B = d->B; a.Hin = d->H; a.Win = d->W;
+    a.H = stride == 2 ? (d->H - 1) / 2 + 1 : d->H;
+    a.W = stride == 2 ? (d->W - 1) / 2 + 1 : d->W;
+    a.Cout = d->Cout; a.nct32 = (d->Cout + 31) / 32;
+    a.act = d->act; a.post_scale = d->post_scale; a.w_unscale = d->weight_unscale;
+    a.add1 = d->addend; a.add2 = d->addend2;
+    a.h = reinterpret_cast<const _Float16*>(d->h); a.h_groups = d->h_groups; a.z = d->z;
+    a.keep_z = d->blend_keep_z; a.hidden = 0;
+    a.out16 = reinterpret_cast<_Float16*>(d->out16); a.out16_groups = d->out16_groups; a.out16_goff = d->out16_group_offset;
+    a.out32 = d->out32; a.out_ctot = d->out_ctot; a.out_coff = d->out_coff;
+    a.npx = 0; a.nct = 0;
+    if (!a.out16 && !a.out32) return TCS_EINVAL;
+    if (a.act == TCS_ACT_RELU_ADD_RELU) return TCS_EUNSUPPORTED;
+    // the packed weight image pads K to a multiple of 64 channels (tcs_conv_packed_floats_f16x3): nk may not exceed it
+    const int kpack = ((d->Cin + 63) / 64) * 4;
+    int kst = d->ksize == 1 ? ((min_k % 4 == 0) ? 4 : 2) : 1;
+    int cfg = d->tile_cfg;
+    if (cfg) kst = (cfg / 10) % 10;
+    if (kst != 1 && kst != 2 && kst != 4) return TCS_EINVAL;
+    for (int i = 0; i < d->n_src; ++i)
+        if (((d->src_ch[i] + 15) / 16) % kst != 0) {
+            // pad the LAST source's k-steps up to the stage size when its tensor and the packed weights hold that much
+            if (i + 1 == d->n_src && d->src_groups[i] >= 2 * (((d->src_ch[i] + 15) / 16 + kst - 1) / kst * kst)) {
+                const int k = (d->src_ch[i] + 15) / 16, kp = (k + kst - 1) / kst * kst;
+                ktot += kp - k;
+                a.src_kend[i] = ktot;
+            } else return TCS_EINVAL;
+        }
+    if (ktot > kpack) return TCS_EINVAL;
+    a.nk = ktot;
+    const int outG = a.out16 ? ((d->epilogue == TCS_EPI_GRU_ZR ? d->Cout / 2 : (d->epilogue == TCS_EPI_DECONV2X ? d->Cout / 4 : d->Cout)) + 7) / 8 : 0;
+    if (a.out16 && (a.out16_goff < 0 || a.out16_goff + outG > a.out16_groups)) return TCS_EINVAL;
+    if (a.out32 && d->epilogue == TCS_EPI_LINEAR && (d->out_coff < 0 || d->out_coff + d->Cout > d->out_ctot)) return TCS_EINVAL;
+    hipStream_t s = tcs_stream(stream);
+    if (!cfg) cfg = s16_heuristic(a, d->ksize, stride, min_k);
+    if (a.nct32 % ((cfg / 1000) % 10) != 0) return TCS_EUNSUPPORTED;          // the cout tile must divide the packed tiles
+
+    switch (d->epilogue) {
+        case TCS_EPI_LINEAR:
+            if (stride == 2) return launch_s16_cfg<3, 2, TCS_EPI_LINEAR>(a, cfg, s);
+            return d->ksize == 3 ? launch_s16_cfg<3, 1, TCS_EPI_LINEAR>(a, cfg, s) : launch_s16_cfg<1, 1, TCS_EPI_LINEAR>(a, cfg, s);
+        case TCS_EPI_DECONV2X:
+            if (d->ksize != 3 || !a.out16 || d->Cout % 32 != 0) return TCS_EINVAL;
+            a.hidden = d->Cout / 4;
+            return launch_s16_cfg<3, 1, TCS_EPI_DECONV2X>(a, cfg, s);
+        case TCS_EPI_GRU_ZR:
+            if (!a.h || !a.out16 || !a.out32 || d->Cout % 64 != 0) return TCS_EINVAL;
+            a.hidden = d->Cout / 2;
+            if (a.h_groups < a.hidden / 8) return TCS_EINVAL;
+            return d->ksize == 3 ? launch_s16_cfg<3, 1, TCS_EPI_GRU_ZR>(a, cfg, s) : launch_s16_cfg<1, 1, TCS_EPI_GRU_ZR>(a, cfg, s);
+        case TCS_EPI_GRU_Q:
+            if (!a.h || !a.z || !a.out16 || d->Cout % 32 != 0) return TCS_EINVAL;
+            a.hidden = d->Cout;
+            if (a.h_groups < a.hidden / 8) return TCS_EINVAL;
+            return d->ksize == 3 ? launch_s16_cfg<3, 1, TCS_EPI_GRU_Q>(a, cfg, s) : launch_s16_cfg<1, 1, TCS_EPI_GRU_Q>(a, cfg, s);
+        default: return TCS_EINVAL;
+    }
+}
+
+}  // extern "C"

@@ -124,3 +124,67 @@ def run_sequence(forward: Callable, seq, iters: int, device, temporal: bool = Tr
         if fs is not None:
             stats.frames.append(fs)
     return stats
+
+
+# ---------------------------------------------------------------------------------------------------
+# real data, when the box has it (BASELINE configs[2]): TartanAir trajectory folder + reference checkpoint
+# ---------------------------------------------------------------------------------------------------
+def _read_rgb(path: str) -> np.ndarray:
+    """PNG -> [3,H,W] float32 0..255 (what evaluate_stereo.py:150-157 hands the model: read_gen + permute + float)."""
+    from PIL import Image
+    with Image.open(path) as im:
+        a = np.asarray(im.convert("RGB"), dtype=np.uint8)
+    return np.ascontiguousarray(a.transpose(2, 0, 1)).astype(np.float32)
+
+
+def load_tartanair_sequence(root: str, max_frames: Optional[int] = None, start: int = 0):
+    """One TartanAir trajectory folder (e.g. .../abandonedfactory/Easy/P000) -> `synth.Sequence`.
+
+    Layout and pairing follow the reference's temporal loader (core/stereo_datasets.py:491-495): sorted
+    `image_left/*_left.png`, `image_right/*_right.png`, `depth_left/*_left_depth.npy`, and `pose_left.txt` with one
+    pose per frame; disparity = 80 / (depth + 1e-5) (frame_utils.py:163-167); intrinsics and baseline are TartanAir's
+    constants (evaluate_stereo.py:138-142).  Returns None (with the reason in `load_tartanair_sequence.why`) when the
+    folder is absent or incomplete: callers then skip BASELINE configs[2] with that logged reason."""
+    import glob
+    import os
+
+    from . import formats, synth
+
+    def miss(why):
+        load_tartanair_sequence.why = why
+        return None
+
+    if not root or not os.path.isdir(root):
+        return miss(f"{root!r} is not a directory")
+    left = sorted(glob.glob(os.path.join(root, "image_left", "*_left.png")))
+    right = sorted(glob.glob(os.path.join(root, "image_right", "*_right.png")))
+    depth = sorted(glob.glob(os.path.join(root, "depth_left", "*_left_depth.npy")))
+    pose_file = os.path.join(root, "pose_left.txt")
+    if not left or len(left) != len(right) or len(left) != len(depth) or not os.path.exists(pose_file):
+        return miss(f"{root}: {len(left)} left / {len(right)} right / {len(depth)} depth files, pose_left.txt "
+                    f"{'present' if os.path.exists(pose_file) else 'missing'}")
+    poses = formats.read_tartanair_extrinsic(pose_file)
+    if len(poses) < len(left):
+        return miss(f"{root}: {len(poses)} poses for {len(left)} frames")
+    stop = len(left) if max_frames is None else min(len(left), start + max_frames)
+    frames = []
+    for i in range(start, stop):
+        disp, _valid = formats.read_disp_tartanair(depth[i])
+        frames.append(synth.Frame(_read_rgb(left[i]), _read_rgb(right[i]), np.asarray(disp, np.float32)[None],
+                                  np.asarray(poses[i], np.float32)))
+    load_tartanair_sequence.why = ""
+    return synth.Sequence(frames, synth.TARTANAIR_K.astype(np.float32), synth.TARTANAIR_BASELINE)
+
+
+load_tartanair_sequence.why = ""
+
+
+def load_checkpoint(model, path: str) -> int:
+    """The reference's `.pth` (evaluate_stereo.py:385-390: `checkpoint['model']`, saved from DataParallel/DDP so keys may
+    carry a `module.` prefix) into `model` with strict=True.  Only a weights-only load is attempted: a file that needs
+    unpickling of arbitrary objects is refused rather than executed.  Returns the number of tensors loaded."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    state = ckpt["model"] if isinstance(ckpt, dict) and "model" in ckpt else ckpt
+    state = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state.items()}
+    model.load_state_dict(state, strict=True)
+    return len(state)

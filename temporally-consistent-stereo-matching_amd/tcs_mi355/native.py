@@ -38,6 +38,22 @@ class ConvDesc(C.Structure):
     ]
 
 
+class ConvS16Desc(C.Structure):
+    """struct tcs_conv_s16_desc (include/tcs_mi355.h)."""
+    _fields_ = [
+        ("src", c_fp * 4), ("src_ch", c_int * 4), ("src_groups", c_int * 4), ("n_src", c_int),
+        ("weight", c_fp), ("bias", c_fp),
+        ("B", c_int), ("H", c_int), ("W", c_int),
+        ("Cin", c_int), ("Cout", c_int), ("ksize", c_int), ("stride", c_int),
+        ("epilogue", c_int), ("act", c_int), ("post_scale", c_f), ("weight_unscale", c_f),
+        ("addend", c_fp), ("addend2", c_fp), ("h", c_fp), ("h_groups", c_int), ("z", c_fp),
+        ("blend_keep_z", c_int),
+        ("out16", c_fp), ("out16_groups", c_int), ("out16_group_offset", c_int),
+        ("out32", c_fp), ("out_ctot", c_int), ("out_coff", c_int),
+        ("tile_cfg", c_int),
+    ]
+
+
 # name -> (restype, argtypes); must list every symbol declared in include/tcs_mi355.h
 SIGNATURES = {
     "tcs_abi_version": (c_int, []),
@@ -76,6 +92,10 @@ SIGNATURES = {
     "tcs_instance_norm": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_f, c_int, c_fp, c_fp, c_fp]),
     "tcs_conv3x3_cout1": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp]),
     "tcs_conv2d": (c_int, [C.POINTER(ConvDesc), c_fp]),
+    "tcs_s16_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
+    "tcs_s16_from_f32": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_int, c_fp]),
+    "tcs_s16_to_f32": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp]),
+    "tcs_conv2d_s16": (c_int, [C.POINTER(ConvS16Desc), c_fp]),
 }
 
 
@@ -114,15 +134,15 @@ def check(rc: int, what: str):
         raise RuntimeError(f"{what} failed: {msg} ({rc})")
 
 
-def ptr(t: torch.Tensor | None, name: str = "tensor"):
-    """Device pointer of a contiguous float32 HIP tensor (None -> NULL)."""
+def ptr(t: torch.Tensor | None, name: str = "tensor", dtype=torch.float32):
+    """Device pointer of a contiguous float32 (or `dtype`) HIP tensor (None -> NULL)."""
     if t is None:
         return None
     if not t.is_cuda:
         raise RuntimeError(f"{name}: tcs_mi355 kernels need a HIP device tensor, got device={t.device} "
                            f"(there is no CPU path; use the oracle only for checking)")
-    if t.dtype != torch.float32:
-        raise ValueError(f"{name}: expected float32, got {t.dtype}")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected {dtype}, got {t.dtype}")
     if not t.is_contiguous():
         raise ValueError(f"{name}: expected a contiguous tensor")
     return t.data_ptr()

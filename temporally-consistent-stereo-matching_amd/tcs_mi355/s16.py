@@ -1,0 +1,213 @@
+"""Pre-split activations ("S16" tensors) and the convolutions that consume them (include/tcs_mi355.h,
+csrc/tcs_conv_s16.hip).
+
+Inside the refinement loop every activation that feeds a convolution lives in the operand form of the
+fp16-split contraction: `_Float16 [B][G][2][H+2][W+2][8]` — groups of 8 channels, {hi, lo} planes with
+x = hi + lo, a one-pixel zero border.  The producer splits once (conv epilogue, stencil kernel); the consumer
+copies 16-byte units straight into LDS.  PyTorch only owns the memory: buffers come from a per-model pool
+(`S16Pool`), zero-filled once so that the border stays zero for the life of the model, and are reused every
+iteration and frame (also what makes the frame capturable without memset nodes).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import native as nv
+from .ops import ACT, EPI_GRU_Q, EPI_GRU_ZR, EPI_LINEAR, MATH_F16X3, PackedConv
+
+EPI_DECONV2X = 3
+
+
+def groups_for(C_: int) -> int:
+    return (C_ + 15) // 16 * 2
+
+
+@dataclass
+class S16:
+    data: torch.Tensor          # float16 [B, G, 2, H+2, W+2, 8]
+    C: int                      # logical channels
+
+    @property
+    def B(self):
+        return int(self.data.shape[0])
+
+    @property
+    def G(self):
+        return int(self.data.shape[1])
+
+    @property
+    def H(self):
+        return int(self.data.shape[3]) - 2
+
+    @property
+    def W(self):
+        return int(self.data.shape[4]) - 2
+
+    @property
+    def device(self):
+        return self.data.device
+
+    def ptr(self):
+        return nv.ptr(self.data, "s16", dtype=torch.float16)
+
+    def float(self) -> torch.Tensor:
+        """fp32 NCHW copy (hi + lo) — the loop's boundary and tests."""
+        return from_s16(self)
+
+
+def zeros(B: int, C_: int, H: int, W: int, device, groups: Optional[int] = None) -> S16:
+    G = groups_for(C_) if groups is None else int(groups)
+    return S16(torch.zeros(B, G, 2, H + 2, W + 2, 8, dtype=torch.float16, device=device), C_)
+
+
+class S16Pool:
+    """Named, zero-initialised S16 buffers that live as long as the model: `get(key, B, C, H, W)` returns the same
+    buffer for the same key and shape.  Producers write interior pixels of real channel groups only, so borders and
+    padding channels stay zero without any per-frame memset."""
+
+    def __init__(self):
+        self.buffers: Dict[tuple, S16] = {}
+
+    def get(self, key, B, C_, H, W, device, groups=None) -> S16:
+        G = groups_for(C_) if groups is None else int(groups)
+        k = (key, B, C_, H, W, G, str(device))
+        buf = self.buffers.get(k)
+        if buf is None:
+            buf = zeros(B, C_, H, W, device, G)
+            self.buffers[k] = buf
+        return buf
+
+    def bytes(self) -> int:
+        return sum(b.data.numel() * 2 for b in self.buffers.values())
+
+
+def to_s16(x: torch.Tensor, out: Optional[S16] = None, group_offset: int = 0) -> S16:
+    """fp32 [B,C,H,W] -> S16 (into groups [group_offset, ...) of `out` when given: a virtual torch.cat)."""
+    if x.ndim != 4:
+        raise ValueError("to_s16 expects [B,C,H,W]")
+    B, C_, H, W = (int(v) for v in x.shape)
+    if out is None:
+        out = zeros(B, C_, H, W, x.device)
+    elif (out.B, out.H, out.W) != (B, H, W):
+        raise ValueError("to_s16: `out` has another shape")
+    nv.check(nv.lib().tcs_s16_from_f32(nv.ptr(x, "x"), B, C_, H, W, out.ptr(), out.G, int(group_offset), nv.stream()), "tcs_s16_from_f32")
+    return out
+
+
+def from_s16(s: S16, C_: Optional[int] = None, group_offset: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    C_ = s.C if C_ is None else int(C_)
+    if out is None:
+        out = torch.empty(s.B, C_, s.H, s.W, dtype=torch.float32, device=s.device)
+    nv.check(nv.lib().tcs_s16_to_f32(s.ptr(), s.B, C_, s.H, s.W, s.G, int(group_offset), nv.ptr(out, "out"), nv.stream()), "tcs_s16_to_f32")
+    return out
+
+
+def _desc(pc: PackedConv, srcs: Sequence[S16], stride: int = 1) -> nv.ConvS16Desc:
+    if pc.math != MATH_F16X3:
+        raise ValueError("S16 convolutions need fp16-split packed weights (pack_conv(..., 'f16x3'))")
+    if not 1 <= len(srcs) <= 4:
+        raise ValueError("1..4 sources")
+    d = nv.ConvS16Desc()
+    B, H, W = srcs[0].B, srcs[0].H, srcs[0].W
+    tot = 0
+    for i, s in enumerate(srcs):
+        if (s.B, s.H, s.W) != (B, H, W):
+            raise ValueError(f"src{i} grid {(s.B, s.H, s.W)} does not match src0 {(B, H, W)}")
+        d.src[i], d.src_ch[i], d.src_groups[i] = s.ptr(), s.C, s.G
+        tot += s.C
+    if tot != pc.cin:
+        raise ValueError(f"sources carry {tot} channels, convolution expects {pc.cin}")
+    d.n_src = len(srcs)
+    d.weight, d.bias = nv.ptr(pc.weight), nv.ptr(pc.bias)
+    d.B, d.H, d.W, d.Cin, d.Cout, d.ksize, d.stride = B, H, W, pc.cin, pc.cout, pc.ksize, stride
+    d.post_scale, d.weight_unscale = 1.0, pc.unscale
+    return d
+
+
+def _out_grid(s: S16, stride: int):
+    return ((s.H - 1) // 2 + 1, (s.W - 1) // 2 + 1) if stride == 2 else (s.H, s.W)
+
+
+def conv2d(pc: PackedConv, srcs: Sequence[S16], act: str = "none", addend: Optional[torch.Tensor] = None, post_scale: float = 1.0,
+           out16: Optional[S16] = None, out16_group_offset: int = 0, out32: Optional[torch.Tensor] = None, out_coff: int = 0,
+           stride: int = 1, want32: bool = False, tile_cfg: int = 0):
+    """act(conv(cat(srcs)) + bias + addend) * post_scale -> S16 (`out16`, allocated when neither output is given)
+    and/or fp32 NCHW (`out32`, or allocated when want32).  Returns (out16, out32)."""
+    d = _desc(pc, srcs, stride)
+    Ho, Wo = _out_grid(srcs[0], stride)
+    if out32 is None and want32:
+        out32 = torch.empty(d.B, pc.cout, Ho, Wo, dtype=torch.float32, device=srcs[0].device)
+    if out16 is None and out32 is None:
+        out16 = zeros(d.B, pc.cout, Ho, Wo, srcs[0].device)
+    if out16 is not None and (out16.B, out16.H, out16.W) != (d.B, Ho, Wo):
+        raise ValueError("conv2d: bad `out16` grid")
+    if out32 is not None and (out32.shape[0] != d.B or tuple(out32.shape[2:]) != (Ho, Wo)):
+        raise ValueError("conv2d: bad `out32` shape")
+    if addend is not None and tuple(addend.shape) != (d.B, pc.cout, Ho, Wo):
+        raise ValueError("conv2d: bad addend shape")
+    d.epilogue, d.act, d.post_scale = EPI_LINEAR, ACT[act], float(post_scale)
+    d.addend = nv.ptr(addend, "addend")
+    if out16 is not None:
+        d.out16, d.out16_groups, d.out16_group_offset = out16.ptr(), out16.G, int(out16_group_offset)
+    if out32 is not None:
+        d.out32, d.out_ctot, d.out_coff = nv.ptr(out32, "out32"), int(out32.shape[1]), int(out_coff)
+    d.tile_cfg = int(tile_cfg)
+    nv.check(nv.lib().tcs_conv2d_s16(C.byref(d), nv.stream()), "tcs_conv2d_s16")
+    return out16, out32
+
+
+def deconv4x4s2(pc: PackedConv, srcs: Sequence[S16], out16: Optional[S16] = None, act: str = "none", tile_cfg: int = 0) -> S16:
+    """ConvTranspose2d(k=4, s=2, p=1, no bias) (+ activation): S16 [B,Cin,H,W] -> S16 [B,Cout,2H,2W]."""
+    d = _desc(pc, srcs)
+    cout = pc.cout // 4
+    if out16 is None:
+        out16 = zeros(d.B, cout, 2 * d.H, 2 * d.W, srcs[0].device)
+    if (out16.B, out16.H, out16.W) != (d.B, 2 * d.H, 2 * d.W):
+        raise ValueError("deconv4x4s2: bad `out16` grid")
+    d.epilogue, d.act = EPI_DECONV2X, ACT[act]
+    d.out16, d.out16_groups, d.out16_group_offset = out16.ptr(), out16.G, 0
+    d.tile_cfg = int(tile_cfg)
+    nv.check(nv.lib().tcs_conv2d_s16(C.byref(d), nv.stream()), "tcs_conv2d_s16[deconv2x]")
+    return out16
+
+
+def gru_gates(pc_zr: PackedConv, srcs: Sequence[S16], h: S16, cz=None, cr=None, z_out: Optional[torch.Tensor] = None,
+              rh_out: Optional[S16] = None, tile_cfg: int = 0):
+    """z = sigmoid(conv_zr[:hid] + cz) (fp32), rh = sigmoid(conv_zr[hid:] + cr) * h (S16)   (update.py:81-83, 30-33)."""
+    d = _desc(pc_zr, srcs)
+    hid = pc_zr.cout // 2
+    if (h.B, h.H, h.W) != (d.B, d.H, d.W) or h.C != hid:
+        raise ValueError("gru_gates: bad h")
+    z_out = torch.empty(d.B, hid, d.H, d.W, dtype=torch.float32, device=h.device) if z_out is None else z_out
+    rh_out = zeros(d.B, hid, d.H, d.W, h.device) if rh_out is None else rh_out
+    d.epilogue = EPI_GRU_ZR
+    d.addend, d.addend2 = nv.ptr(cz, "cz"), nv.ptr(cr, "cr")
+    d.h, d.h_groups = h.ptr(), h.G
+    d.out32, d.out_ctot, d.out_coff = nv.ptr(z_out, "z"), hid, 0
+    d.out16, d.out16_groups, d.out16_group_offset = rh_out.ptr(), rh_out.G, 0
+    d.tile_cfg = int(tile_cfg)
+    nv.check(nv.lib().tcs_conv2d_s16(C.byref(d), nv.stream()), "tcs_conv2d_s16[gru_zr]")
+    return z_out, rh_out
+
+
+def gru_update(pc_q: PackedConv, srcs: Sequence[S16], h: S16, z: torch.Tensor, cq=None, keep_z: bool = False,
+               out: Optional[S16] = None, out32: Optional[torch.Tensor] = None, tile_cfg: int = 0) -> S16:
+    """q = tanh(conv_q + cq); h' = (1-z)h + zq (keep_z=False, update.py:85) or zh + (1-z)q (update.py:34,66).
+    `out` may be `h` itself (in-place state update: each element is read and written by the same lane)."""
+    d = _desc(pc_q, srcs)
+    if (h.B, h.H, h.W) != (d.B, d.H, d.W) or h.C != pc_q.cout or tuple(z.shape) != (d.B, pc_q.cout, d.H, d.W):
+        raise ValueError("gru_update: bad h/z")
+    out = zeros(d.B, pc_q.cout, d.H, d.W, h.device) if out is None else out
+    d.epilogue = EPI_GRU_Q
+    d.addend, d.z, d.blend_keep_z = nv.ptr(cq, "cq"), nv.ptr(z, "z"), int(keep_z)
+    d.h, d.h_groups = h.ptr(), h.G
+    d.out16, d.out16_groups, d.out16_group_offset = out.ptr(), out.G, 0
+    if out32 is not None:
+        d.out32, d.out_ctot, d.out_coff = nv.ptr(out32, "out32"), pc_q.cout, 0
+    d.tile_cfg = int(tile_cfg)
+    nv.check(nv.lib().tcs_conv2d_s16(C.byref(d), nv.stream()), "tcs_conv2d_s16[gru_q]")
+    return out

@@ -203,6 +203,51 @@ def test_bench_spawns_its_own_ranks():
     assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
 
 
+def test_tartanair_folder_and_checkpoint_loaders(tmp_path, key_shapes):
+    """BASELINE configs[2] plumbing on a constructed 2-frame trajectory folder: file pairing, PNG decoding, depth->disparity,
+    pose parsing, and the weights-only checkpoint path with DataParallel-style `module.` keys (parity unpinned by reference
+    outputs: the reference's readers need cv2 / imageio, which are absent here)."""
+    from PIL import Image
+    from tcs_mi355 import harness
+    from tcs_mi355.weights import synth_state_dict
+    root = tmp_path / "abandonedfactory" / "Easy" / "P000"
+    for d in ("image_left", "image_right", "depth_left"):
+        (root / d).mkdir(parents=True)
+    rng = np.random.default_rng(0)
+    imgs = rng.integers(0, 256, size=(2, 2, 480, 640, 3), dtype=np.uint8)
+    depth = rng.uniform(1.0, 30.0, size=(2, 480, 640)).astype(np.float32)
+    for i in range(2):
+        Image.fromarray(imgs[i, 0]).save(root / "image_left" / f"{i:06d}_left.png")
+        Image.fromarray(imgs[i, 1]).save(root / "image_right" / f"{i:06d}_right.png")
+        np.save(root / "depth_left" / f"{i:06d}_left_depth.npy", depth[i])
+    (root / "pose_left.txt").write_text("0 0 0 0 0 0 1\n0.1 0.0 0.0 0 0 0 1\n")
+    seq = harness.load_tartanair_sequence(str(root))
+    assert seq is not None and len(seq.frames) == 2 and seq.baseline == 0.25
+    f1 = seq.frames[1]
+    assert f1.image1.shape == (3, 480, 640) and f1.image1.dtype == np.float32
+    assert np.array_equal(f1.image1, imgs[1, 0].transpose(2, 0, 1).astype(np.float32))
+    assert np.array_equal(f1.image2, imgs[1, 1].transpose(2, 0, 1).astype(np.float32))
+    assert np.allclose(f1.disp_gt[0], 80.0 / (depth[1] + 1e-5))
+    # camera 0.1 m along NED x (forward) -> world->camera translation -0.1 along camera z
+    assert np.allclose(f1.T[:3, 3], [0, 0, -0.1], atol=1e-6) and np.allclose(seq.frames[0].T, np.eye(4)[[1, 2, 0, 3]] @ np.eye(4), atol=1e-6)
+    assert harness.load_tartanair_sequence(str(tmp_path / "nope")) is None and "not a directory" in harness.load_tartanair_sequence.why
+    (root / "pose_left.txt").unlink()
+    assert harness.load_tartanair_sequence(str(root)) is None and "pose_left.txt missing" in harness.load_tartanair_sequence.why
+    # checkpoint: {'model': state_dict with 'module.' prefixes}
+    from core.tc_stereo import TCStereo
+    W = synth_state_dict(key_shapes["shared_backbone"])
+    torch.save({"model": {"module." + k: v for k, v in W.items()}, "optimizer": {}}, tmp_path / "tc.pth")
+    m = TCStereo(_args())
+    assert harness.load_checkpoint(m, str(tmp_path / "tc.pth")) == len(W)
+    k0 = "update_block.gru08.convq.weight"
+    assert torch.equal(m.state_dict()[k0], W[k0])
+    bad = dict(W)
+    bad.pop(k0)
+    torch.save({"model": bad}, tmp_path / "bad.pth")
+    with pytest.raises(RuntimeError):
+        harness.load_checkpoint(TCStereo(_args()), str(tmp_path / "bad.pth"))
+
+
 def test_formats_known_answers(tmp_path):
     """N2 file formats.  The reference readers (core/utils/frame_utils.py) cannot be imported here (cv2 /
     imageio are absent), so these are known-answer checks against scipy's Rotation — the function the

@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""Micro-benchmark + self-check of tcs_conv2d_s16 (pre-split activations, LDS-DMA staging) against tcs_conv2d (fp32 NCHW in,
+on-the-fly split) on the refinement loop's layer shapes (GPU box).  For every shape and tile configuration: max abs difference
+to the old kernel's output (both contract the same fp16 halves, so they agree to fp32 summation order) and us per launch from
+a HIP-graph replay of a burst of launches timed with HIP events.
+usage: bench_conv_s16.py [only-substring] ; env CFGS=1413,2413,... restricts the tile configurations."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import tcs_paths; tcs_paths.add_product_path()
+import torch
+from tcs_mi355 import ops, s16
+
+dev = torch.device("cuda:0")
+SHAPES = [  # name, (cins...), cout, k, H, W, epilogue, stride
+    ("gru08.zr", (128, 128, 128), 256, 3, 120, 160, "zr", 1),
+    ("gru08.q", (128, 128, 128), 128, 3, 120, 160, "q", 1),
+    ("conv128->256", (128,), 256, 3, 120, 160, "lin", 1),
+    ("conv192->128", (96, 96), 128, 3, 120, 160, "lin", 1),
+    ("conv128->128", (128,), 128, 3, 120, 160, "lin", 1),
+    ("conv64->64", (64,), 64, 3, 120, 160, "lin", 1),
+    ("conv160->64", (32, 64, 64), 64, 3, 120, 160, "lin", 1),
+    ("gru16.zr", (128, 128, 128), 256, 3, 60, 80, "zr", 1),
+    ("gru16.q", (128, 128, 128), 128, 3, 60, 80, "q", 1),
+    ("gru32.zr", (128, 128), 256, 3, 30, 40, "zr", 1),
+    ("conv96->96/8", (96,), 96, 3, 60, 80, "lin", 1),
+    ("conv192->128/16", (128, 64), 128, 3, 30, 40, "lin", 1),
+    ("1x1 192->256", (128, 64), 256, 1, 120, 160, "zr", 1),
+    ("1x1 192->128", (128, 64), 128, 1, 120, 160, "q", 1),
+    ("1x1 27->96", (27,), 96, 1, 120, 160, "lin", 1),
+    ("1x1 96->96", (96,), 96, 1, 120, 160, "lin", 1),
+    ("1x1 128->9", (128,), 9, 1, 120, 160, "lin", 1),
+    ("s2 64->96", (64,), 96, 3, 120, 160, "lin", 2),
+    ("deconv 128->96", (128,), 96, 3, 30, 40, "deconv", 1),
+]
+CFGS3 = [1412, 1512, 2512, 1812, 2812, 11412, 11413, 12412, 12413, 12414, 12512, 12513, 11513, 12812, 12813, 14412, 14413]
+CFGS1 = [1422, 1423, 2422, 2423, 1442, 1443, 2442, 2443]
+only = sys.argv[1] if len(sys.argv) > 1 else ""
+forced = [int(c) for c in os.environ.get("CFGS", "").split(",") if c]
+gen = torch.Generator().manual_seed(0)
+
+
+def timed(run, n=100, reps=3):
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(n):
+                run()
+    g.replay()
+    torch.cuda.synchronize()
+    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        g.replay()
+    e.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(e) * 1e3 / (n * reps)
+
+
+for name, cins, cout, k, H, W, epi, stride in SHAPES:
+    if only and only not in name:
+        continue
+    cin = sum(cins)
+    xs = [torch.randn(1, c, H, W, generator=gen).to(dev) for c in cins]
+    hid = cout // 2 if epi == "zr" else cout
+    h = torch.randn(1, hid, H, W, generator=gen).to(dev)
+    z = torch.rand(1, hid, H, W, generator=gen).to(dev)
+    if epi == "deconv":
+        wt = (torch.randn(cin, cout, 4, 4, generator=gen) * 0.02).to(dev)
+        pc = ops.pack_deconv4x4s2(wt)
+    else:
+        w = (torch.randn(cout, cin, k, k, generator=gen) * 0.02).to(dev)
+        b = (torch.randn(cout, generator=gen) * 0.1).to(dev)
+        pc = ops.pack_conv(w, b, "f16x3")
+    add = torch.randn(1, hid if epi in ("zr", "q") else cout, (H - 1) // stride + 1, (W - 1) // stride + 1, generator=gen).to(dev)
+    xs16 = [s16.to_s16(x) for x in xs]
+    h16 = s16.to_s16(h)
+
+    def old():
+        if epi == "zr":
+            return ops.gru_gates(pc, xs, h, add, add)
+        if epi == "q":
+            return (ops.gru_update(pc, xs, h, z, add),)
+        if epi == "deconv":
+            return (ops.deconv4x4s2(pc, xs),)
+        return (ops.conv2d(pc, xs, act="relu", addend=add, stride=stride),)
+
+    outs = {}
+
+    def new(cfg):
+        if epi == "zr":
+            zz, rh = s16.gru_gates(pc, xs16, h16, add, add, z_out=outs.get("z"), rh_out=outs.get("rh"), tile_cfg=cfg)
+            outs.update(z=zz, rh=rh)
+            return zz, rh
+        if epi == "q":
+            o = s16.gru_update(pc, xs16, h16, z, add, out=outs.get("o"), tile_cfg=cfg)
+            outs.update(o=o)
+            return (o,)
+        if epi == "deconv":
+            o = s16.deconv4x4s2(pc, xs16, out16=outs.get("o"), tile_cfg=cfg)
+            outs.update(o=o)
+            return (o,)
+        o16, o32 = s16.conv2d(pc, xs16, act="relu", addend=add, stride=stride, out16=outs.get("o16"), out32=outs.get("o32"), want32=True,
+                              tile_cfg=cfg)
+        if outs.get("o16") is None:
+            outs.update(o16=s16.zeros(1, cout, o32.shape[2], o32.shape[3], dev), o32=o32)
+        return (o32,)
+
+    ref = [t.clone() for t in old()]
+    t_old = timed(old)
+    macs = ((H - 1) // stride + 1) * ((W - 1) // stride + 1) * cin * cout * k * k
+    line = f"{name:16s} {H}x{W} cin {cin:4d} cout {cout:4d}: old {t_old:7.1f} us {2.0 * macs / t_old / 1e6:6.1f} TF |"
+    cfgs = forced or ([0] + (CFGS1 if k == 1 else ([1412] if stride == 2 else CFGS3)))
+    for cfg in cfgs:
+        try:
+            got = new(cfg)
+        except RuntimeError as e:
+            if "unsupported" in str(e) or "invalid" in str(e):
+                continue
+            raise
+        errs = []
+        for gi, r in zip(got, ref):
+            gt = gi.float() if isinstance(gi, s16.S16) else gi
+            errs.append(float((gt - r).abs().max()) / max(1.0, float(r.abs().max())))
+        if epi in ("lin",) and outs.get("o16") is not None:       # the S16 copy of a LINEAR output must equal its fp32 copy
+            s16.conv2d(pc, xs16, act="relu", addend=add, stride=stride, out16=outs["o16"], out32=None, tile_cfg=cfg)
+            errs.append(float((outs["o16"].float() - ref[0]).abs().max()) / max(1.0, float(ref[0].abs().max())))
+        t_new = timed(lambda: new(cfg))
+        flag = "" if max(errs) < 2e-5 else f" !!ERR {max(errs):.1e}"
+        line += f" {cfg}:{t_new:6.1f}{flag}"
+    print(line, flush=True)
+    outs.clear()
