@@ -234,6 +234,10 @@ typedef struct tcs_conv_desc {
     int stride;              /* 0 or 1: 'same' convolution; 2: 3x3 stride-2 pad-1 (F16X3 only), output (H-1)/2+1 x (W-1)/2+1 */
     int math;                /* TCS_MATH_F32: weights from tcs_pack_conv_weight; TCS_MATH_F16X3: from ..._f16x3 */
     float weight_unscale;    /* F16X3: 2^-scale_log2 given to tcs_pack_conv_weight_f16x3 */
+    void* out16;             /* LINEAR, stride 1: optional S16 ("pre-split", see below) copy of the output, so that a layer fed by a
+                                fp32 tensor (correlation features, disparity stencils) hands its result to tcs_conv2d_s16 consumers
+                                without a conversion pass; `out` may then be NULL */
+    int out16_groups, out16_group_offset;
 } tcs_conv_desc;
 
 /* packed weight size in floats for a [Cout,Cin,k,k] convolution */
@@ -313,8 +317,25 @@ typedef struct tcs_conv_s16_desc {
     float* out32;            /* fp32 NCHW output: LINEAR (nullable; [B,out_ctot,Ho,Wo] at channel out_coff); GRU_ZR: z (required);
                                 GRU_Q: optional fp32 copy of the new h */
     int out_ctot, out_coff;
-    int tile_cfg;            /* 0 = choose by grid size; otherwise MT*1000 + ROWS*100 + KSTEPS*10 + NSTAGE (benchmarks, tests) */
+    int tile_cfg;            /* 0 = choose by grid size; otherwise CSPLIT*100000 + RS*10000 + MT*1000 + ROWS*100 + KSTEPS*10 + NSTAGE
+                                (benchmarks, tests; csrc/tcs_conv_s16.hip) */
 } tcs_conv_s16_desc;
+
+/* S16 glue of the loop: pool2x / interp (core/update.py:114-124), the up-blocks' InstanceNorm + LeakyReLU + skip
+ * (core/utils/basic_layers.py:28-35,65-76), DispRefine's candidate stencil (core/update.py:259-289: 27 channels into 4 groups
+ * for the 1x1 stem, the 9 candidates also as fp32 for the blend), one fp32 channel into an S16 tensor, and the blend
+ * kernel writing the next iteration's flow input into a channel of the S16 motion features (core/update.py:126). */
+int tcs_avgpool3s2_s16(const void* x, int B, int groups, int H, int W, void* out, int out_groups, tcs_stream_t stream);
+int tcs_resize_bilinear_s16(const void* x, int B, int groups, int H, int W, int Ho, int Wo, void* out, int out_groups, tcs_stream_t stream);
+size_t tcs_instance_norm_s16_workspace_bytes(int B, int groups, int H, int W);
+int tcs_instance_norm_s16(const void* x, int B, int groups, int H, int W, float eps, int act, const void* addend, int addend_groups,
+                          void* out, int out_groups, void* workspace, tcs_stream_t stream);
+int tcs_propagate_disparity_s16(const float* grad, const float* disp, int B, int H, int W, float* cand9, void* out16, int out_groups,
+                                tcs_stream_t stream);
+int tcs_s16_set_channel(const float* x, int B, int H, int W, void* s16, int groups_total, int channel, tcs_stream_t stream);
+int tcs_softmax_blend_s16(const float* logits9, const float* cand, int cand_ctot, const float* disp_q,
+                          int B, int H, int W, float* refined, float* delta_disp, float* coords1, float* flow_x,
+                          void* flow_x_s16, int flow_x_s16_groups, int flow_x_s16_channel, tcs_stream_t stream);
 
 /* nn.Conv2d / ConvGRU step on S16 activations (core/update.py:16-17,26-36,57-68,77-87,103-111,198-214,291-305) */
 int tcs_conv2d_s16(const tcs_conv_s16_desc* desc, tcs_stream_t stream);

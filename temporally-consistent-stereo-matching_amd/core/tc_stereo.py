@@ -21,7 +21,7 @@ from core.extractor import BasicEncoder, MultiBasicEncoder, ResidualBlock, hip_h
 from core.update import (BasicMultiUpdateBlock, DispGradPredictor, DispRefine, DisparityCompletor, HiddenstateUpdater,
                          Lightfuse, hip_conv)
 from core.utils.utils import coords_grid
-from tcs_mi355 import ops
+from tcs_mi355 import ops, s16
 
 
 class autocast(contextlib.AbstractContextManager):
@@ -55,6 +55,11 @@ class TCStereo(nn.Module):
         self.disp_refine = DispRefine(args)
         self.context_zqr_convs_grad = nn.ModuleList([nn.Conv2d(hd[i], 64, 3, padding=1) for i in range(n)])
         self.hiddenstate_update = HiddenstateUpdater(hd[0])
+        # one pool of pre-split ("S16") activation buffers for the whole model: allocated (zero-filled) on first use,
+        # reused every iteration and frame (tcs_mi355/s16.py)
+        pool = s16.S16Pool()
+        for m in self.modules():
+            m._s16pool = pool
 
     def freeze_bn(self):
         for m in self.modules():
@@ -171,33 +176,40 @@ class TCStereo(nn.Module):
             trace.update(sparse_disp=sparse_disp, cost=cost, sparse_mask=sparse_mask, disp_init=disp_init,
                          net0=[t.clone() for t in net_list], iters=[])
 
+        # ---- refinement loop on pre-split activations (tcs_mi355/s16.py): hidden states, context features and the motion
+        # feature buffer live in S16 pool buffers; 1-2 channel geometry (coords, disparity, gradients) stays fp32 ----
+        pool = self._s16pool
         n3 = a.n_gru_layers == 3
+        nets = [s16.to_s16(t.float().contiguous(), out=pool.get(("frame", "net", i), t.shape[0], t.shape[1], t.shape[2], t.shape[3], t.device))
+                for i, t in enumerate(net_list)]
+        grads16 = [s16.to_s16(t.float().contiguous(), out=pool.get(("frame", "ctxg", i), t.shape[0], t.shape[1], t.shape[2], t.shape[3], t.device))
+                   for i, t in enumerate(grad_list)]
         refined = up_mask = None
         # coords1 - coords0, the motion encoder's flow input (tc_stereo.py:180): once here, afterwards the blend kernel writes
         # it for the next iteration — as a tensor for the 7x7 stem and into channel 127 of the motion feature buffer
-        flows_x = coords1 - coords0
-        motion_buf = torch.empty(coords1.shape[0], 128, coords1.shape[2], coords1.shape[3], dtype=torch.float32, device=coords1.device)
-        motion_buf[:, 127:128].copy_(flows_x)
+        flows_x = (coords1 - coords0).contiguous()
+        motion = pool.get(("frame", "motion"), coords1.shape[0], 128, coords1.shape[2], coords1.shape[3], coords1.device)
+        s16.set_channel(flows_x, motion, 127)
+        ub = self.update_block
         for itr in range(iters):
             corr = corr_fn(coords1)
             if n3 and a.slow_fast_gru:
-                net_list = self.update_block(net_list, inp_list, iter32=True, iter16=False, iter08=False, update=False)
+                ub.run(pool, nets, inp_list, None, None, None, iter32=True, iter16=False, iter08=False, update=False)
             if a.n_gru_layers >= 2 and a.slow_fast_gru:
-                net_list = self.update_block(net_list, inp_list, iter32=n3, iter16=True, iter08=False, update=False)
-            net_list, delta_flow = self.update_block(net_list, inp_list, corr, flows_x, iter32=n3, iter16=a.n_gru_layers >= 2,
-                                                     motion_out=motion_buf)
+                ub.run(pool, nets, inp_list, None, None, None, iter32=n3, iter16=True, iter08=False, update=False)
+            delta_flow = ub.run(pool, nets, inp_list, corr, flows_x, motion, iter32=n3, iter16=a.n_gru_layers >= 2)
             # disp_q = x - (coords1 + delta), 5 * disp2disp_gradient_xy (update.py:199) and the gradient candidates in one
             # launch; coords1 is replaced by the blend kernel's output below
             disp_q, g5, cands = ops.flow_step_grads(coords1, delta_flow, scale=5.0)
-            disp_grad, context = self.disp_grad_refine(None, disp_q, grad_list, g5=g5, cands=cands)
+            disp_grad, context = self.disp_grad_refine.run(pool, g5, cands, grads16)
             last = itr == iters - 1
-            fused = {"flow_x_channel": motion_buf[:, 127:128]}
-            refined, up_mask = self.disp_refine(disp_grad, disp_q, net_list[0], context, test_mode=not last, fused_outputs=fused)
-            net_list = [self.hiddenstate_update(net_list[0], fused["delta_disp"]), net_list[1], net_list[2]]
+            refined, up_mask, fused = self.disp_refine.run(pool, disp_grad, disp_q, nets[0], context, want_mask=last, motion=motion)
+            self.hiddenstate_update.run(pool, nets[0], fused["delta_disp"])
             coords1, flows_x = fused["coords1"], fused["flow_x"]
             if trace is not None:
                 trace["iters"].append(dict(corr=corr, delta=delta_flow, disp_q=disp_q, refined=refined,
-                                           net=[t.clone() for t in net_list]))
+                                           net=[t.float() for t in nets]))
+        net_list = [t.float() for t in nets]
 
         flow_up, flow_q = ops.convex_upsample(refined.contiguous(), up_mask)
         return {"flow": flow_up, "flow_q": flow_q, "net_list": [x.detach() for x in net_list], "fmap1": fmap1.detach()}

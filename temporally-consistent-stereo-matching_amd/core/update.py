@@ -7,6 +7,11 @@ a ConvGRU is two launches instead of ~15 ATen ops, and the 24 host-synchronising
 iteration of the reference (update.py:27-35,58-67,78-86,155-158) are gone.  Every layer — including
 the stride-2 convs, the transposed-conv + InstanceNorm up-blocks of both U-Nets and the
 DisparityCompletor — runs on the HIP library; nothing here calls MIOpen.
+
+Two tensor formats.  The reference-facing `forward` of every module takes and returns fp32 NCHW tensors.  Inside
+the refinement loop the activations stay in the convolutions' operand form ("S16", tcs_mi355/s16.py): the `run`
+methods take and return S16 tensors out of a per-model buffer pool, and `forward` is a thin conversion wrapper
+around `run`, so module-level parity tests exercise exactly the kernels the frame uses.
 """
 import os
 
@@ -15,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from core.utils.basic_layers import Conv2x_IN
-from tcs_mi355 import ops
+from tcs_mi355 import ops, s16
 from tcs_mi355.streams import fork_join
 
 
@@ -42,6 +47,70 @@ def packed(conv: nn.Conv2d) -> ops.PackedConv:
         hit = (key, ops.pack_conv(w, b, math))
         conv._tcs_packed = hit
     return hit[1]
+
+
+def packed16(conv: nn.Conv2d) -> ops.PackedConv:
+    """fp16-split packing whatever TCS_MI355_MATH says: the S16 kernels contract fp16 halves by construction."""
+    if getattr(conv, "_tcs_math", None) == "f32" or CONV_MATH != "f16x3":
+        w, b = conv.weight, conv.bias
+        key = (w.data_ptr(), w._version, w.device, None if b is None else (b.data_ptr(), b._version))
+        hit = getattr(conv, "_tcs_packed16", None)
+        if hit is None or hit[0] != key:
+            hit = (key, ops.pack_conv(w, b, "f16x3"))
+            conv._tcs_packed16 = hit
+        return hit[1]
+    return packed(conv)
+
+
+def pool_of(module) -> s16.S16Pool:
+    """The S16 buffer pool of the model a module belongs to (TCStereo shares one; a stand-alone module gets its own)."""
+    p = getattr(module, "_s16pool", None)
+    if p is None:
+        p = s16.S16Pool()
+        for m in module.modules():
+            m._s16pool = p
+    return p
+
+
+def conv16(pool, conv, srcs, act="none", addend=None, post_scale=1.0, out=None, want32=False, tag="o"):
+    """A Conv2d on S16 sources -> S16 (a pool buffer owned by this conv, or `out`), or fp32 NCHW when want32."""
+    a = srcs[0]
+    stride = conv.stride[0]
+    Ho, Wo = ((a.H - 1) // 2 + 1, (a.W - 1) // 2 + 1) if stride == 2 else (a.H, a.W)
+    if want32:
+        return s16.conv2d(packed16(conv), srcs, act=act, addend=addend, post_scale=post_scale, want32=True, stride=stride)[1]
+    if out is None:
+        out = pool.get((id(conv), tag), a.B, conv.out_channels, Ho, Wo, a.device)
+    return s16.conv2d(packed16(conv), srcs, act=act, addend=addend, post_scale=post_scale, out16=out, stride=stride)[0]
+
+
+def conv32to16(pool, conv, x, act="none", tag="o"):
+    """A Conv2d fed by a fp32 NCHW tensor (correlation features, disparity stencils, single-channel maps) writing S16."""
+    B, _, H, W = (int(v) for v in x.shape)
+    out = pool.get((id(conv), tag), B, conv.out_channels, H, W, x.device)
+    return ops.conv2d(packed(conv), [x.float().contiguous()], act=act, out16=out)
+
+
+def to16(pool, x, key):
+    B, C_, H, W = (int(v) for v in x.shape)
+    return s16.to_s16(x.float().contiguous(), out=pool.get(key, B, C_, H, W, x.device))
+
+
+def up_block16(pool, block: Conv2x_IN, x: s16.S16, rem: s16.S16) -> s16.S16:
+    """Conv2x_IN(deconv=True, concat=False) on S16 tensors: transposed conv -> InstanceNorm -> LeakyReLU -> + rem ->
+    3x3 conv [-> InstanceNorm] -> LeakyReLU (basic_layers.py:38-77)."""
+    dc = block.conv1.conv
+    y = s16.deconv4x4s2(packed_deconv(dc), [x], out16=pool.get((id(dc), "o"), x.B, dc.out_channels, 2 * x.H, 2 * x.W, x.device))
+    if (y.H, y.W) != (rem.H, rem.W):         # odd-sized skip: nearest resize as the reference does (rare; through fp32)
+        y32 = F.interpolate(s16.instance_norm(y, act="leaky", out=y).float(), size=(rem.H, rem.W), mode="nearest") + rem.float()
+        y = to16(pool, y32, (id(dc), "resized"))
+    else:
+        y = s16.instance_norm(y, act="leaky", addend=rem, out=y)
+    act2 = "leaky" if block.conv2.relu else "none"
+    if block.conv2.use_in:
+        z = conv16(pool, block.conv2.conv, [y])
+        return s16.instance_norm(z, act=act2, out=z)
+    return conv16(pool, block.conv2.conv, [y], act=act2)
 
 
 def hip_conv(conv, srcs, act="none", **kw):
@@ -118,6 +187,13 @@ class _GateCell(nn.Module):
         z, rh = ops.gru_gates(packed(self.convzr), [h, *xs], h, cz, cr)
         return ops.gru_update(packed(self.convq), [rh, *xs], h, z, cq, keep_z=self.keep_z)
 
+    def step16(self, pool, h: s16.S16, xs, cz=None, cr=None, cq=None) -> s16.S16:
+        """The same cell on S16 tensors, updating `h` IN PLACE (two launches; z stays fp32, r*h is an S16 temporary)."""
+        z = pool.get32((id(self), "z"), (h.B, h.C, h.H, h.W), h.device)
+        rh = pool.get((id(self), "rh"), h.B, h.C, h.H, h.W, h.device)
+        s16.gru_gates(packed16(self.convzr), [h, *xs], h, cz, cr, z_out=z, rh_out=rh)
+        return s16.gru_update(packed16(self.convq), [rh, *xs], h, z, cq, keep_z=self.keep_z, out=h)
+
 
 class ConvGRU(_GateCell):
     def __init__(self, hidden_dim, input_dim, kernel_size=3):
@@ -149,8 +225,14 @@ class HiddenstateUpdater(_GateCell):
         super().__init__(hidden_dim, 64, 1)
         self.convs = nn.Sequential(_conv(1, 64, 1), nn.LeakyReLU(inplace=True), _conv(64, 64, 1))
 
+    def run(self, pool, h: s16.S16, delta: torch.Tensor) -> s16.S16:
+        x = conv32to16(pool, self.convs[0], delta, act="leaky")              # 1 -> 64 (single-channel kernel)
+        x = conv16(pool, self.convs[2], [x])
+        return self.step16(pool, h, [x])
+
     def forward(self, h, x):
-        return self._step(h, [hip_seq(self.convs, [x])])
+        pool = pool_of(self)
+        return self.run(pool, to16(pool, h, (id(self), "h_in")), x.float().contiguous()).float()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -163,11 +245,15 @@ class FlowHead(nn.Module):
         self.conv2 = _conv(hidden_dim, output_dim, 3)
         self.relu = nn.ReLU(inplace=True)
 
+    def run(self, pool, x: s16.S16) -> torch.Tensor:
+        """-> fp32 [B,out,H,W].  The 256 -> 1 head runs on the S16 kernel too: one 32-wide tile of which one row is real costs
+        ~10 us, less than the fp32 reduction kernel it replaces (15.6 us), and needs no fp32 copy of the 256 channels."""
+        y = conv16(pool, self.conv1, [x], act="relu")
+        return conv16(pool, self.conv2, [y], want32=True)
+
     def forward(self, x):
-        y = hip_conv(self.conv1, [x], act="relu")
-        if self.conv2.out_channels == 1:
-            return ops.conv3x3_cout1(y, self.conv2.weight, self.conv2.bias)      # 256 -> 1: reduction kernel, not a 32-wide MFMA tile
-        return hip_conv(self.conv2, [y])
+        pool = pool_of(self)
+        return self.run(pool, to16(pool, x, (id(self), "x_in")))
 
 
 class BasicMotionEncoder(nn.Module):
@@ -182,20 +268,29 @@ class BasicMotionEncoder(nn.Module):
         self.conv = _conv(128, 127, 3)
 
     def forward(self, flow, corr, out=None):
-        """`out`, when given, is a [N,128,H,W] buffer whose channel 127 ALREADY holds `flow` (the blend kernel of the
-        previous iteration writes it there): only channels 0..126 are produced here."""
+        """cat(features(126 + 1), flow) [N,128,H,W] fp32 (update.py:103-111); `out`, when given, receives it."""
         flow = flow.float().contiguous()
-        cor, flo = fork_join([
-            lambda: hip_conv(self.convc2, [hip_conv(self.convc1, [corr], act="relu")], act="relu"),
-            lambda: hip_conv(self.convf2, [hip_conv(self.convf1, [flow], act="relu")], act="relu")], site="enc")
+        pool = pool_of(self)
         n, _, h, w = flow.shape
-        prefilled = out is not None
-        if not prefilled:
-            out = torch.empty(n, 128, h, w, dtype=torch.float32, device=flow.device)
-        hip_conv(self.conv, [cor, flo], act="relu", out=out)     # channels 0..126 in place: no torch.cat
-        if not prefilled:
-            out[:, 127:128].copy_(flow)
-        return out
+        motion = pool.get((id(self), "motion_api"), n, 128, h, w, flow.device)
+        s16.set_channel(flow, motion, 127)
+        res = self.run(pool, flow, corr.float().contiguous(), motion).float()
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
+
+    def run(self, pool, flow: torch.Tensor, corr: torch.Tensor, motion: s16.S16) -> s16.S16:
+        """`motion`: the S16 [N,128,H,W] motion feature buffer whose channel 127 ALREADY holds `flow`; channels 0..126 are
+        written here (the 127-channel epilogue never touches channel 127: masked partial store)."""
+        def cor():
+            return conv16(pool, self.convc2, [conv32to16(pool, self.convc1, corr, act="relu")], act="relu")
+
+        def flo():
+            return conv16(pool, self.convf2, [conv32to16(pool, self.convf1, flow, act="relu")], act="relu")
+
+        c, f = fork_join([cor, flo], site="enc")
+        return conv16(pool, self.conv, [c, f], act="relu", out=motion)
 
 
 def pool2x(x):
@@ -227,29 +322,51 @@ class BasicMultiUpdateBlock(nn.Module):
                     nn.init.constant_(m.bias, 0)
 
     def forward(self, net, inp, corr=None, flow=None, iter08=True, iter16=True, iter32=True, update=True, motion_out=None):
-        """Coarse-to-fine GRU sweep (update.py:145-168); `net` is updated in place like the reference.
-        `motion_out`: see BasicMotionEncoder.forward(out=...)."""
+        """Coarse-to-fine GRU sweep (update.py:145-168) on fp32 tensors; returns the new `net` list (+ delta_flow)."""
+        pool = pool_of(self)
+        net16 = [to16(pool, t, (id(self), "net_in", i)) for i, t in enumerate(net)]
+        motion = None
+        if iter08:
+            flow = flow.float().contiguous()
+            motion = pool.get((id(self), "motion_api"), flow.shape[0], 128, flow.shape[2], flow.shape[3], flow.device)
+            s16.set_channel(flow, motion, 127)
+        inp = [[t.float().contiguous() for t in trio] for trio in inp]
+        res = self.run(pool, net16, inp, None if corr is None else corr.float().contiguous(), flow, motion, iter08, iter16, iter32, update)
+        out = [n.float() for n in net16]
+        if motion_out is not None and motion is not None:
+            motion_out.copy_(motion.float())
+        return (out, res) if update else out
+
+    def run(self, pool, net, inp, corr, flow, motion, iter08=True, iter16=True, iter32=True, update=True):
+        """`net`: list of S16 hidden states, updated IN PLACE; `inp`: per scale (cz, cr, cq) fp32; returns delta_flow (fp32)
+        when `update`."""
         n = self.args.n_gru_layers
 
         def coarse():            # gru32 -> gru16: independent of the motion encoder (which only feeds gru08)
             if iter32:
-                net[2] = self.gru32(net[2], *inp[2], pool2x(net[1]))
+                p = s16.avgpool3s2(net[1], out=pool.get((id(self), "pool16"), net[2].B, net[1].C, net[2].H, net[2].W, net[2].device))
+                self.gru32.step16(pool, net[2], [p], *inp[2])
             if iter16:
-                extra = (interp(net[2], net[1]),) if n > 2 else ()
-                net[1] = self.gru16(net[1], *inp[1], pool2x(net[0]), *extra)
-            return interp(net[1], net[0]) if (iter08 and n > 1) else None
+                xs = [s16.avgpool3s2(net[0], out=pool.get((id(self), "pool08"), net[1].B, net[0].C, net[1].H, net[1].W, net[1].device))]
+                if n > 2:
+                    xs.append(s16.resize_bilinear(net[2], net[1].H, net[1].W,
+                                                  out=pool.get((id(self), "up32"), net[1].B, net[2].C, net[1].H, net[1].W, net[1].device)))
+                self.gru16.step16(pool, net[1], xs, *inp[1])
+            if iter08 and n > 1:
+                return s16.resize_bilinear(net[1], net[0].H, net[0].W,
+                                           out=pool.get((id(self), "up16"), net[0].B, net[1].C, net[0].H, net[0].W, net[0].device))
+            return None
 
         if iter08:
             # the encoder (which forks again) stays on the current stream: ROCm 7.2 segfaults in hipStreamEndCapture when
             # a side branch of a captured fork forks a second time
-            motion, up16 = fork_join([lambda: self.encoder(flow, corr, out=motion_out), coarse], site="coarse")
-            extra = (up16,) if n > 1 else ()
-            net[0] = self.gru08(net[0], *inp[0], motion, *extra)
+            m, up16 = fork_join([lambda: self.encoder.run(pool, flow, corr, motion), coarse], site="coarse")
+            self.gru08.step16(pool, net[0], [m] + ([up16] if n > 1 else []), *inp[0])
         else:
             coarse()
         if not update:
-            return net
-        return net, self.flow_head(net[0])
+            return None
+        return self.flow_head.run(pool, net[0])
 
 
 # ---------------------------------------------------------------------------------------------
@@ -274,31 +391,43 @@ class DispGradPredictor(nn.Module):
         self.residual_head = _two(64, 128, 2)
         self.conv_out = nn.Sequential(_conv(64, 64, 3), relu())
 
-    def _up(self, block: Conv2x_IN, x, rem):
-        return hip_up_block(block, x, rem)
-
     def forward(self, disp_grad, disp, clist, g5=None, cands=None):
-        """`g5`, when given, is 5*disp_grad already produced by the gradient kernel (saves an elementwise launch)."""
+        """fp32 API (update.py:198-214): -> (refined gradient [N,2,H,W], context [N,64,H,W]).  `g5`, when given, is
+        5*disp_grad already produced by the gradient kernel; `cands` the gradient candidates of `disp`."""
         disp = disp.float().contiguous()
         if g5 is None:
-            g5 = (5 * disp_grad).contiguous()                    # update.py:199
+            g5 = (5 * disp_grad).float().contiguous()            # update.py:199
         if cands is None:
             cands = ops.grad_candidates(disp)                    # [N,32,H,W] (update.py:202-204)
-        x4_grad, x4_cand = fork_join([lambda: hip_seq(self.conv_grad_stem, [g5]),
-                                      lambda: hip_seq(self.conv_grad_candidate_stem, [cands])], site="stems")
-        x4 = hip_seq(self.conv_4_4, [x4_grad, x4_cand, clist[0]])
-        x8 = hip_seq(self.conv_4_8, [x4])                                       # 3x3 stride 2
-        x8 = hip_seq(self.conv_8_8, [x8, clist[1]])
-        x16 = hip_seq(self.conv_8_16, [x8])                                     # 3x3 stride 2
-        x16 = hip_seq(self.conv_16_16, [x16, clist[2]])
-        x8_up = self._up(self.conv_16_8, x16, x8)
-        x4_up = self._up(self.conv_8_4, x8_up, x4)
+        pool = pool_of(self)
+        c16 = [to16(pool, c, (id(self), "clist_in", i)) for i, c in enumerate(clist)]
+        grad, ctx = self.run(pool, g5, cands, c16)
+        return grad, ctx.float()
+
+    def run(self, pool, g5: torch.Tensor, cands: torch.Tensor, clist):
+        """g5 = 5 * gradient [N,2,H,W] fp32, cands [N,32,H,W] fp32, clist: 3 S16 context tensors (64 ch at 1/4, 1/8, 1/16)
+        -> (gradient fp32 [N,2,H,W], context S16 [N,64,H,W])."""
+        def stem_g():
+            return conv16(pool, self.conv_grad_stem[2], [conv32to16(pool, self.conv_grad_stem[0], g5, act="relu")])
+
+        def stem_c():
+            return conv16(pool, self.conv_grad_candidate_stem[2], [conv32to16(pool, self.conv_grad_candidate_stem[0], cands, act="relu")])
+
+        x4_grad, x4_cand = fork_join([stem_g, stem_c], site="stems")
+        x4 = conv16(pool, self.conv_4_4[0], [x4_grad, x4_cand, clist[0]], act="relu")
+        x8 = conv16(pool, self.conv_4_8[0], [x4], act="relu")                    # 3x3 stride 2
+        x8 = conv16(pool, self.conv_8_8[0], [x8, clist[1]], act="relu")
+        x16 = conv16(pool, self.conv_8_16[0], [x8], act="relu")                  # 3x3 stride 2
+        x16 = conv16(pool, self.conv_16_16[0], [x16, clist[2]], act="relu")
+        x8_up = up_block16(pool, self.conv_16_8, x16, x8)
+        x4_up = up_block16(pool, self.conv_8_4, x8_up, x4)
+
         def head():
             # (5*grad + residual) / 5 (update.py:213) in the epilogue of the last conv: addend = 5*grad, scale = 1/5
-            h = hip_conv(self.residual_head[0], [x4_up], act="relu")
-            return hip_conv(self.residual_head[2], [h], addend=g5, post_scale=0.2)
+            h = conv16(pool, self.residual_head[0], [x4_up], act="relu")
+            return conv16(pool, self.residual_head[2], [h], addend=g5, post_scale=0.2, want32=True)
 
-        grad, ctx = fork_join([head, lambda: hip_seq(self.conv_out, [x4_up])], site="heads")
+        grad, ctx = fork_join([head, lambda: conv16(pool, self.conv_out[0], [x4_up], act="relu")], site="heads")
         return grad, ctx
 
 
@@ -313,37 +442,47 @@ class DispRefine(nn.Module):
         factor = 2 ** args.n_downsample
         self.mask = nn.Sequential(_conv(128, 256, 3), nn.ReLU(inplace=True), _conv(256, factor * factor * 9, 1))
 
-    def _prop(self, disparity_grad, disparity_map):
-        return ops.propagate_disparity(disparity_grad.float().contiguous(), disparity_map.float().contiguous())
-
     def propagate_disparity(self, disparity_grad, disparity_map):
         """9 gradient-extrapolated neighbour candidates + 18 gradient differences (update.py:259-289)."""
-        buf = self._prop(disparity_grad, disparity_map)
+        buf = ops.propagate_disparity(disparity_grad.float().contiguous(), disparity_map.float().contiguous())
         return buf[:, :9], buf[:, 9:]
 
     def forward(self, disp_grads, disp, context_disp, context_grad, test_mode=False, fused_outputs=None):
-        """`fused_outputs`, when a dict, receives 'delta_disp' (= refined - disp) and 'coords1' (= x - refined) straight
-        from the blend kernel (tc_stereo.py:198-202), saving two elementwise launches."""
-        disp = disp.float().contiguous()
-        def cand_branch():
-            f27 = self._prop(disp_grads, disp)                    # cat(candidates, matrix) laid out by the kernel
-            return f27, hip_seq(self.disp_f_stem, [f27])
-
-        context, (feats27, disp_f) = fork_join([lambda: hip_seq(self.context_compress, [context_disp, context_grad]), cand_branch], site="refine")
-        fused = hip_seq(self.conv_fuse, [disp_f, context])
-        logits = hip_seq(self.w_head, [fused])
+        """fp32 API (update.py:291-305): -> (refined disparity, 0.25 * upsampling mask or None when test_mode).
+        `fused_outputs`, when a dict, receives 'delta_disp' (= refined - disp), 'coords1' (= x - refined) and 'flow_x'."""
+        pool = pool_of(self)
+        cd = to16(pool, context_disp, (id(self), "ctxd_in"))
+        cg = to16(pool, context_grad, (id(self), "ctxg_in"))
+        refined, mask, extra = self.run(pool, disp_grads.float().contiguous(), disp.float().contiguous(), cd, cg, want_mask=not test_mode)
         if fused_outputs is not None:
-            coords1 = torch.empty_like(disp)
-            flow_x = torch.empty_like(disp)
-            refined, delta = ops.softmax_blend(logits, feats27, disp_q=disp, want_delta=True, coords1=coords1, flow_x=flow_x,
-                                               flow_x_channel=fused_outputs.get("flow_x_channel"))
-            fused_outputs.update(delta_disp=delta, coords1=coords1, flow_x=flow_x)
-        else:
-            refined, _ = ops.softmax_blend(logits, feats27)
-        mask = None
-        if not test_mode:
-            mask = hip_conv(self.mask[2], [hip_conv(self.mask[0], [fused], act="relu")], post_scale=0.25)
+            fused_outputs.update(extra)
         return refined, mask
+
+    def run(self, pool, disp_grads: torch.Tensor, disp: torch.Tensor, context_disp: s16.S16, context_grad: s16.S16, want_mask=False,
+            motion: s16.S16 = None):
+        """-> (refined fp32, mask fp32 or None, dict(delta_disp, coords1, flow_x)).  With `motion`, the next iteration's flow input
+        (coords1 - x) also lands in channel 127 of that S16 buffer (tc_stereo.py:180, update.py:126)."""
+        def cand_branch():
+            f27, cand9 = s16.propagate_disparity(disp_grads, disp, out16=pool.get((id(self), "f27"), disp.shape[0], 27, disp.shape[2], disp.shape[3], disp.device))
+            d = conv16(pool, self.disp_f_stem[0], [f27], act="relu")
+            return cand9, conv16(pool, self.disp_f_stem[2], [d])
+
+        def ctx_branch():
+            c = conv16(pool, self.context_compress[0], [context_disp, context_grad], act="relu")
+            return conv16(pool, self.context_compress[2], [c])
+
+        context, (cand9, disp_f) = fork_join([ctx_branch, cand_branch], site="refine")
+        fused = conv16(pool, self.conv_fuse[0], [disp_f, context], act="relu")
+        fused = conv16(pool, self.conv_fuse[2], [fused], act="relu")
+        w = conv16(pool, self.w_head[0], [fused], act="relu")
+        logits = conv16(pool, self.w_head[2], [w], want32=True)
+        coords1, flow_x = torch.empty_like(disp), torch.empty_like(disp)
+        refined, delta = s16.softmax_blend(logits, cand9, disp, coords1, flow_x, flow_x_s16=motion, flow_x_channel=127)
+        mask = None
+        if want_mask:
+            m = conv16(pool, self.mask[0], [fused], act="relu")
+            mask = conv16(pool, self.mask[2], [m], post_scale=0.25, want32=True)
+        return refined, mask, dict(delta_disp=delta, coords1=coords1, flow_x=flow_x)
 
 
 # ---------------------------------------------------------------------------------------------

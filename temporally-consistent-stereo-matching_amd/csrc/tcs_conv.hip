@@ -129,6 +129,30 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a) {
     for (int m = 0; m < MT; ++m) conv_epilogue_tile<EPI>(a, b, ct * NT + m * 32 + 4 * half, pix, HW, acc[m], 1.0f);
 }
 
+// epilogue of the single-input-channel kernels: 16 output channels co_lo .. co_lo+15 of one pixel -> fp32 NCHW and/or S16
+__device__ __forceinline__ void cin1_store16(const ConvArgs& a, int b, int co_lo, int y, int x, int p, int HW, const float* acc) {
+    float v[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int co = min(co_lo + c, a.Cout - 1);
+        float t = acc[c] + (a.bias ? a.bias[co] : 0.f);
+        if (a.add1) t += a.add1[((size_t)b * a.Cout + co) * HW + p];
+        v[c] = co_lo + c < a.Cout ? apply_act(t, a.act) * a.post_scale : 0.f;
+    }
+    if (a.out) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (co_lo + c < a.Cout) a.out[((size_t)b * a.out_ctot + a.out_coff + co_lo + c) * HW + p] = v[c];
+    }
+    if (a.out16) {                                      // two 8-channel units (Cout is a multiple of 8 on this path)
+        const int Hp = a.H + 2, Wp = a.W + 2;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+            if (co_lo + 8 * g < a.Cout)
+                s16_store8(a.out16 + s16_unit(b, a.out16_groups, a.out16_goff + (co_lo >> 3) + g, 0, Hp, Wp, y, x), (size_t)Hp * Wp * 8, v + 8 * g);
+    }
+}
+
 // Single-input-channel convolutions (BasicMotionEncoder.convf1 7x7, HiddenstateUpdater.convs.0 1x1):
 // K is too small for the matrix cores to pay; one thread per pixel, 16 output channels per block.z,
 // weights are wave-uniform (scalar loads).
@@ -173,15 +197,7 @@ __global__ __launch_bounds__(256) void k_conv_cin1(ConvArgs a) {
         if (t % KS == KS - 1) { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
     }
     if (!active) return;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        const int co = co_lo + c;
-        if (co < a.Cout) {
-            float v = acc[c] + (a.bias ? a.bias[co] : 0.f);
-            if (a.add1) v += a.add1[((size_t)b * a.Cout + co) * HW + p];
-            a.out[((size_t)b * a.out_ctot + a.out_coff + co) * HW + p] = apply_act(v, a.act) * a.post_scale;
-        }
-    }
+    cin1_store16(a, b, co_lo, y, x, p, HW, acc);
 }
 
 // 7x7 stem on a 1-channel input (BasicMotionEncoder.convf1, update.py:113): 64 x 4 pixel tile per block, the tile
@@ -224,16 +240,7 @@ __global__ __launch_bounds__(256) void k_conv7x7_cin1(ConvArgs a) {
     }
     const int x = tx0 + lx, y = ty0 + ly;
     if (x >= W || y >= H) return;
-    const int p = y * W + x;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        const int co = co_lo + c;
-        if (co < a.Cout) {
-            float v = acc[c] + (a.bias ? a.bias[co] : 0.f);
-            if (a.add1) v += a.add1[((size_t)b * a.Cout + co) * HW + p];
-            a.out[((size_t)b * a.out_ctot + a.out_coff + co) * HW + p] = apply_act(v, a.act) * a.post_scale;
-        }
-    }
+    cin1_store16(a, b, co_lo, y, x, y * W + x, HW, acc);
 }
 
 __global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ w, int Cout, int Cin, int taps, int CinPad, int CoutPad,
@@ -292,7 +299,11 @@ int tcs_pack_conv_weight(const float* w_oihw, int Cout, int Cin, int ksize, floa
 }
 
 int tcs_conv2d(const tcs_conv_desc* d, tcs_stream_t stream) {
-    if (!d || !d->weight || !d->out) return TCS_EINVAL;
+    if (!d || !d->weight || (!d->out && !d->out16)) return TCS_EINVAL;
+    if (d->out16 && (d->epilogue != TCS_EPI_LINEAR || d->stride == 2 || d->out16_group_offset < 0 ||
+                     d->out16_group_offset + (d->Cout + 7) / 8 > d->out16_groups || (d->Cin == 1 && d->Cout % 8 != 0)))
+        return TCS_EINVAL;
+    if (!d->out && d->epilogue != TCS_EPI_LINEAR) return TCS_EINVAL;
     if (d->n_src < 1 || d->n_src > TCS_MAX_SRC) return TCS_EINVAL;
     if (d->B <= 0 || d->B > 65535 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0) return TCS_EINVAL;
     ConvArgs a;
@@ -316,6 +327,7 @@ int tcs_conv2d(const tcs_conv_desc* d, tcs_stream_t stream) {
     a.add1 = d->addend; a.add2 = d->addend2; a.h = d->h; a.z = d->z;
     a.keep_z = d->blend_keep_z; a.hidden = 0;
     a.out = d->out; a.out_ctot = d->out_ctot; a.out_coff = d->out_coff; a.out2 = d->out2;
+    a.out16 = reinterpret_cast<_Float16*>(d->out16); a.out16_groups = d->out16_groups; a.out16_goff = d->out16_group_offset;
     a.npx = tcs_cdiv(d->W, 32);
     a.npatch = a.npx * tcs_cdiv(d->H, 4);
     a.nct = a.CoutPad / nt;
@@ -326,7 +338,7 @@ int tcs_conv2d(const tcs_conv_desc* d, tcs_stream_t stream) {
     if (d->math == TCS_MATH_F16X3) {
         // fp16-split matrix-core path (tcs_conv_f16.hip); weights must come from tcs_pack_conv_weight_f16x3
         if (d->Cin == 1 || (d->ksize != 1 && d->ksize != 3)) return TCS_EUNSUPPORTED;
-        if (d->epilogue == TCS_EPI_LINEAR && (d->out_ctot < d->out_coff + d->Cout || d->out_coff < 0)) return TCS_EINVAL;
+        if (d->epilogue == TCS_EPI_LINEAR && d->out && (d->out_ctot < d->out_coff + d->Cout || d->out_coff < 0)) return TCS_EINVAL;
         const bool gru = d->epilogue == TCS_EPI_GRU_ZR || d->epilogue == TCS_EPI_GRU_Q;
         if (gru && !d->h) return TCS_EINVAL;
         if (d->epilogue == TCS_EPI_GRU_ZR && (!d->out2 || (d->Cout & 1))) return TCS_EINVAL;
@@ -344,7 +356,7 @@ int tcs_conv2d(const tcs_conv_desc* d, tcs_stream_t stream) {
     if (stride != 1 || d->epilogue == TCS_EPI_DECONV2X) return TCS_EUNSUPPORTED;      // fp32 kernel: stride-1 'same' only
 
     if (d->epilogue == TCS_EPI_LINEAR) {
-        if (d->out_ctot < d->out_coff + d->Cout || d->out_coff < 0) return TCS_EINVAL;
+        if (d->out && (d->out_ctot < d->out_coff + d->Cout || d->out_coff < 0)) return TCS_EINVAL;
         if (d->Cin == 1) {
             const dim3 grid(tcs_cdiv((long long)d->H * d->W, 256), d->B, tcs_cdiv(d->Cout, 16));
             if (d->ksize == 1) hipLaunchKernelGGL(k_conv_cin1<1>, grid, dim3(256), 0, s, a);

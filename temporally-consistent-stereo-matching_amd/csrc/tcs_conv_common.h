@@ -1,6 +1,7 @@
 // Shared pieces of the two convolution kernels (fp32 MFMA: tcs_conv.hip, fp16-split MFMA: tcs_conv_f16.hip).
 #pragma once
 #include "tcs_common.h"
+#include "tcs_s16.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -27,6 +28,8 @@ struct ConvArgs {
     int src_align8;         // every source boundary is a multiple of 8 channels (one source select per 8-channel group)
     int w_bytes;            // size of the packed weight buffer (buffer-load bound)
     float w_unscale;        // fp16-split kernel: 2^-s undoing the weight pre-scale (1 for the fp32 kernel)
+    _Float16* out16;        // LINEAR: optional S16 copy of the output (tcs_s16.h), written at group offset out16_goff
+    int out16_groups, out16_goff;
 };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -101,8 +104,24 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, int b, int
         }
         const int act = late ? TCS_ACT_RELU : a.act;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (ok[r]) a.out[((size_t)b * a.out_ctot + a.out_coff + cc[r]) * HW + pix] = apply_act(v[r], act) * a.post_scale;
+        for (int r = 0; r < 16; ++r) v[r] = apply_act(v[r], act) * a.post_scale;
+        if (a.out) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (ok[r]) a.out[((size_t)b * a.out_ctot + a.out_coff + cc[r]) * HW + pix] = v[r];
+        }
+        if (a.out16) {
+            // the 4 registers 4q..4q+3 are 4 consecutive channels of group (co0 >> 3) + q: one 8-byte store per {hi, lo}
+            const int Hp = a.H + 2, Wp = a.W + 2, py = (int)(pix / a.W), px = (int)(pix - (size_t)py * a.W);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c_first = co0 + 8 * q;
+                if (c_first < a.Cout) {
+                    _Float16* o = a.out16 + s16_unit(b, a.out16_groups, a.out16_goff + (c_first >> 3), 0, Hp, Wp, py, px) + (co0 & 4);
+                    s16_store4(o, (size_t)Hp * Wp * 8, &v[4 * q], a.Cout - c_first);
+                }
+            }
+        }
     } else if (EPI == TCS_EPI_GRU_ZR) {
         // channel < hidden: z = sigmoid(. + cz) -> out ; else r = sigmoid(. + cr), out2 = r * h
         size_t o[16];

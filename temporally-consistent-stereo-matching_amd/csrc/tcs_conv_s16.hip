@@ -26,11 +26,8 @@
 // Epilogues (bias, fp32 addends, activation, GRU gate arithmetic, pixel shuffle of the transposed convs) run on the
 // accumulators and write S16 (8-byte stores: 4 channels of one pixel, hi or lo) and/or fp32 NCHW.
 #include "tcs_conv_common.h"
+#include "tcs_s16.h"
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-typedef float float2_t __attribute__((ext_vector_type(2)));
 typedef float float4_t __attribute__((ext_vector_type(4)));
 
 struct S16Args {
@@ -56,29 +53,10 @@ struct S16Args {
     float* out32;                       // fp32 NCHW output (nullable): LINEAR out / GRU_ZR z
     int out_ctot, out_coff;
     int npx, nct;
+    int npatch, csplit;                 // block -> (patch, cout tile) mapping, see s16_block_tile()
+    int ablate;                         // diagnostic builds only (-DTCS_S16_ABLATE, tools/conv_s16_ablate.py): bit 0 skip the
+                                        // input DMA, bit 1 skip the weight DMA, bit 2 skip operand reads + MFMAs (timing only)
 };
-
-// ---------------------------------------------------------------------------------------------------------------------
-// S16 element access helpers (epilogues, conversion kernels)
-// ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void split4(const float* v, half4& hi, half4& lo) {
-    // x = hi + lo (+ <= 2^-22 |x|); saturates at +-65504 (a NaN stays a NaN: fmed3 returns it... see s16_sat_flag)
-#pragma unroll
-    for (int j = 0; j < 4; j += 2) {
-        float2_t x;
-        x[0] = __builtin_amdgcn_fmed3f(v[j], -65504.f, 65504.f);
-        x[1] = __builtin_amdgcn_fmed3f(v[j + 1], -65504.f, 65504.f);
-        const half2_t h2 = __builtin_convertvector(x, half2_t);
-        const float2_t back = __builtin_convertvector(h2, float2_t);
-        const half2_t l2 = __builtin_convertvector(x - back, half2_t);
-        hi[j] = h2[0]; hi[j + 1] = h2[1]; lo[j] = l2[0]; lo[j + 1] = l2[1];
-    }
-}
-
-// offset (in halves) of unit (b, g, hl, y, x) of an S16 tensor with G groups on an H x W grid (interior coordinates)
-__device__ __forceinline__ size_t s16_unit(int b, int G, int g, int hl, int Hp, int Wp, int y, int x) {
-    return ((((size_t)b * G + g) * 2 + hl) * Hp + (y + 1)) * (size_t)Wp * 8 + (size_t)(x + 1) * 8;
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // epilogue of one 32(cout) x 32(pixel) accumulator tile; lane = pixel, register r -> channel co0 + (r&3) + 8*(r>>2)
@@ -123,13 +101,10 @@ __device__ __forceinline__ void s16_epilogue_tile(const S16Args& a, int b, int c
         if (a.out16) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int g = (co0 >> 3) + q;
-                if (g * 8 < ((a.Cout + 7) & ~7)) {                   // groups that hold real channels
-                    half4 hi, lo;
-                    split4(&v[4 * q], hi, lo);
+                const int g = (co0 >> 3) + q, c_first = co0 + 8 * q;  // 4 consecutive channels c_first .. c_first + 3
+                if (c_first < a.Cout) {
                     _Float16* o = a.out16 + s16_unit(b, a.out16_groups, a.out16_goff + g, 0, Hp, Wp, py, px) + sub4;
-                    *reinterpret_cast<half4*>(o) = hi;
-                    *reinterpret_cast<half4*>(o + (size_t)Hp * Wp * 8) = lo;
+                    s16_store4(o, (size_t)Hp * Wp * 8, &v[4 * q], a.Cout - c_first);
                 }
             }
         }
@@ -231,12 +206,39 @@ __device__ __forceinline__ void s16_epilogue_tile(const S16Args& a, int b, int c
 // 2x instead of 1.5x (L2-resident), but a stage shrinks from 49 to 21 KiB (MT = 2), so that two or three workgroups fit a CU
 // with the 64-channel tile: the 32-channel tile (4 LDS reads per 3 MFMAs) is LDS-bandwidth bound, and one workgroup per CU
 // cannot hide its own DMA latency and barriers.
+// Block -> (pixel patch, cout tile).  The hardware deals workgroups round-robin over the 8 XCDs (blocks b and b+8 share an
+// XCD and its 4 MiB L2; placement is a speed matter only).  A pixel patch's activations are read by every cout tile and a
+// cout tile's weights by every patch; only one of the two streams can be made L2-resident per XCD:
+//   csplit = 0: cout tile = b % nct — with nct in {1,2,4,8} each XCD sees ONE weight slice but streams ALL activations
+//               (each activation byte then leaves the Infinity Cache 8 times).
+//   csplit = S >= 1: the cout tiles are cut into S groups; the blocks one XCD receives are a contiguous run of the order
+//               (group, patch, tile in group): an XCD works through a run of patches doing ALL tiles of the group for each,
+//               so an activation tile is fetched from the Infinity Cache once per group and hits L2 for the other tiles.
+__device__ __forceinline__ void s16_block_tile(const S16Args& a, int bid, int nblocks, int& patch, int& ct) {
+    if (a.csplit <= 0) { ct = bid % a.nct; patch = bid / a.nct; return; }
+    const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7;                 // bijective XCD-contiguous renumbering
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tg = a.nct / a.csplit;                                            // tiles per group
+    const int per_group = a.npatch * tg;
+    const int grp = v / per_group, w = v - grp * per_group;
+    patch = w / tg;
+    ct = grp * tg + (w - patch * tg);
+}
+
 // a wave-uniform pointer the compiler may have parked in VGPRs (SGPR pressure): back to an SGPR pair for the "s" operand
 __device__ __forceinline__ const char* uniform_ptr(const char* p) {
     const unsigned long long u = reinterpret_cast<unsigned long long>(p);
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
     return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
 }
+
+#ifdef TCS_S16_ABLATE
+#define S16_ABL_DMA(IS_INPUT) (!(a.ablate & ((IS_INPUT) ? 1 : 2)))
+#define S16_ABL_COMPUTE (!(a.ablate & 4))
+#else
+#define S16_ABL_DMA(IS_INPUT) true
+#define S16_ABL_COMPUTE true
+#endif
 
 template <int KS, int MT, int ROWS, int KSTEPS, int NSTAGE, int STRIDE, int EPI, int RS = 0>
 __global__ __launch_bounds__(64 * ROWS) void k_conv_s16(S16Args a) {
@@ -253,8 +255,8 @@ __global__ __launch_bounds__(64 * ROWS) void k_conv_s16(S16Args a) {
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bid = blockIdx.x;
-    const int ct = bid % a.nct, patch = bid / a.nct;
+    int ct, patch;
+    s16_block_tile(a, blockIdx.x, gridDim.x, patch, ct);
     const int b = blockIdx.y;
     const int y0 = (patch / a.npx) * ROWS, x0 = (patch % a.npx) * 32;
     const int Hp = a.Hin + 2, Wp = a.Win + 2;
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(64 * ROWS) void k_conv_s16(S16Args a) {
         _Pragma("unroll") for (int j = 0; j < PPW; ++j) {                                                             \
             const int p_ = min(wave + j * ROWS, NP - 1);                                                              \
             const char* base_ = p_ < NPI ? in_ptr_ : w_ptr_;                                                          \
-            S16_DMA(voff[j], dst0_ + (unsigned)p_ * 1024u, base_)                                                     \
+            if (S16_ABL_DMA(p_ < NPI)) S16_DMA(voff[j], dst0_ + (unsigned)p_ * 1024u, base_)                          \
         }                                                                                                             \
     }
 
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(64 * ROWS) void k_conv_s16(S16Args a) {
             nb = nb >= NSTAGE ? nb - NSTAGE : nb;
             S16_ISSUE(nb, s + NSTAGE - 1)
         }
-        {
+        if (S16_ABL_COMPUTE) {
             const unsigned addr_b = addr_b0 + (unsigned)buf * STAGE_BYTES, addr_a = addr_a0 + (unsigned)buf * STAGE_BYTES;
             Frag f0, f1;
             S16_FETCH(f0, 0)
@@ -448,11 +450,14 @@ static int launch_s16(S16Args& a, hipStream_t s) {
     }
     a.npx = tcs_cdiv(a.W, 32);
     a.nct = a.nct32 / MT;
-    hipLaunchKernelGGL(kern, dim3(a.npx * tcs_cdiv(a.H, ROWS) * a.nct, a.B), dim3(64 * ROWS), lds, s, a);
+    a.npatch = a.npx * tcs_cdiv(a.H, ROWS);
+    if (a.csplit > 0 && a.nct % a.csplit != 0) a.csplit = 1;
+    hipLaunchKernelGGL(kern, dim3(a.npatch * a.nct, a.B), dim3(64 * ROWS), lds, s, a);
     return tcs_launch_status();
 }
 
-// tile configuration: cfg = RS*10000 + MT*1000 + ROWS*100 + KSTEPS*10 + NSTAGE (0 = heuristic); unknown combinations -> EUNSUPPORTED
+// tile configuration: cfg = CSPLIT*100000 + RS*10000 + MT*1000 + ROWS*100 + KSTEPS*10 + NSTAGE (0 = heuristic; CSPLIT: see
+// s16_block_tile); unknown combinations -> EUNSUPPORTED
 template <int KS, int STRIDE, int EPI>
 static int launch_s16_cfg(S16Args& a, int cfg, hipStream_t s) {
 #define S16_CASE(MT_, ROWS_, KST_, NST_) \
@@ -462,11 +467,9 @@ static int launch_s16_cfg(S16Args& a, int cfg, hipStream_t s) {
     if constexpr (KS == 3 && STRIDE == 1) {
         switch (cfg) {
             S16_CASE(1, 4, 1, 2) S16_CASE(1, 4, 1, 3) S16_CASE(2, 4, 1, 2) S16_CASE(2, 4, 1, 3)
-            S16_CASE(1, 5, 1, 2) S16_CASE(1, 5, 1, 3) S16_CASE(2, 5, 1, 2) S16_CASE(2, 5, 1, 3)
-            S16_CASE(1, 8, 1, 2) S16_CASE(1, 8, 1, 3) S16_CASE(2, 8, 1, 2)
-            S16_CASE_RS(1, 4, 1, 2) S16_CASE_RS(1, 4, 1, 3) S16_CASE_RS(2, 4, 1, 2) S16_CASE_RS(2, 4, 1, 3) S16_CASE_RS(2, 4, 1, 4)
-            S16_CASE_RS(2, 5, 1, 2) S16_CASE_RS(2, 5, 1, 3) S16_CASE_RS(1, 5, 1, 3)
-            S16_CASE_RS(2, 8, 1, 2) S16_CASE_RS(2, 8, 1, 3) S16_CASE_RS(4, 4, 1, 2) S16_CASE_RS(4, 4, 1, 3)
+            S16_CASE(1, 5, 1, 2) S16_CASE(2, 5, 1, 2)
+            S16_CASE(1, 8, 1, 2) S16_CASE(2, 8, 1, 2)
+            S16_CASE_RS(2, 4, 1, 2) S16_CASE_RS(2, 4, 1, 3)
             default: return TCS_EUNSUPPORTED;
         }
     } else if constexpr (KS == 3) {
@@ -476,8 +479,9 @@ static int launch_s16_cfg(S16Args& a, int cfg, hipStream_t s) {
         }
     } else {
         switch (cfg) {
+            S16_CASE(1, 4, 1, 2) S16_CASE(2, 4, 1, 2)
             S16_CASE(1, 4, 2, 2) S16_CASE(1, 4, 2, 3) S16_CASE(2, 4, 2, 2) S16_CASE(2, 4, 2, 3)
-            S16_CASE(1, 4, 4, 2) S16_CASE(1, 4, 4, 3) S16_CASE(2, 4, 4, 2) S16_CASE(2, 4, 4, 3)
+            S16_CASE(1, 4, 4, 2) S16_CASE(2, 4, 4, 2)
             default: return TCS_EUNSUPPORTED;
         }
     }
@@ -485,17 +489,25 @@ static int launch_s16_cfg(S16Args& a, int cfg, hipStream_t s) {
 #undef S16_CASE_RS
 }
 
-static int s16_heuristic(const S16Args& a, int ksize, int stride, int min_src_ksteps) {
+// Tile choice by grid size, from the layer sweep of tools/bench_conv_s16.py on MI355X (gpurun_out/r2_s16_c.log):
+//  * 3x3 on grids that give >= 180 workgroups with 8-row patches: ROWS = 8, two stages (8 waves share one weight image; 80 KiB
+//    of LDS, so two workgroups per CU); the 64-channel tile only for Cout = 128 layers with >= 192 input channels
+//    (gru08.q 72 -> 59 us, 192->128 35.6 -> 34.4 us), where it halves an otherwise 1.2-per-CU grid;
+//  * smaller grids (1/8 scale with 128 outputs, 1/16 scale, transposed convs): 4-row patches, 32-channel tiles;
+//  * 1x1: two k-steps per stage; 64-channel tiles for Cout >= 256;
+//  * CSPLIT = 1 (all cout tiles of a patch on one XCD, s16_block_tile): 0-3 % on 3x3, 20-30 % on the 1x1 layers.
+static int s16_heuristic(const S16Args& a, int ksize, int stride, int kst1x1) {
     if (ksize == 1) {
-        const int kst = (min_src_ksteps % 4 == 0) ? 4 : 2;
-        const long long blocks2 = (long long)tcs_cdiv(a.W, 32) * tcs_cdiv(a.H, 4) * a.B * (a.nct32 / 2);
-        const int mt = (a.nct32 % 2 == 0 && blocks2 >= 512) ? 2 : 1;
-        return mt * 1000 + 400 + kst * 10 + 3;
+        const int mt = (a.nct32 % 2 == 0 && a.nct32 >= 8) ? 2 : 1;
+        return 100000 + mt * 1000 + 400 + kst1x1 * 10 + 2;
     }
     if (stride == 2) return 1412;
-    const long long px4 = (long long)tcs_cdiv(a.W, 32) * tcs_cdiv(a.H, 4) * a.B;
-    const int mt = (a.nct32 % 2 == 0 && px4 * (a.nct32 / 2) >= 512) ? 2 : 1;
-    return mt * 1000 + 400 + 10 + 3;
+    const long long blocks8 = (long long)tcs_cdiv(a.W, 32) * tcs_cdiv(a.H, 8) * a.B * a.nct32;
+    if (blocks8 >= 180) {
+        const int mt = (a.nct32 == 4 && a.nk >= 12 && blocks8 >= 280) ? 2 : 1;
+        return 100000 + mt * 1000 + 800 + 10 + 2;
+    }
+    return 100000 + 1000 + 400 + 10 + 2;
 }
 
 extern "C" {
@@ -533,7 +545,7 @@ int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
     const int stride = d->stride == 2 ? 2 : 1;
     if (stride == 2 && (d->ksize != 3 || d->epilogue != TCS_EPI_LINEAR)) return TCS_EUNSUPPORTED;
     S16Args a;
-    int ktot = 0, min_k = 1 << 30, cin = 0;
+    int ktot = 0, cin = 0;
     for (int i = 0; i < TCS_MAX_SRC; ++i) {
         const bool used = i < d->n_src;
         if (used) {
@@ -542,7 +554,6 @@ int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
             if (i + 1 < d->n_src && d->src_ch[i] % 16 != 0) return TCS_EINVAL;
             const int k = (d->src_ch[i] + 15) / 16;
             ktot += k;
-            min_k = k < min_k ? k : min_k;
             cin += d->src_ch[i];
         }
         a.src[i] = reinterpret_cast<const _Float16*>(used ? d->src[i] : d->src[0]);
@@ -561,13 +572,20 @@ int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
     a.keep_z = d->blend_keep_z; a.hidden = 0;
     a.out16 = reinterpret_cast<_Float16*>(d->out16); a.out16_groups = d->out16_groups; a.out16_goff = d->out16_group_offset;
     a.out32 = d->out32; a.out_ctot = d->out_ctot; a.out_coff = d->out_coff;
-    a.npx = 0; a.nct = 0;
+    a.npx = 0; a.nct = 0; a.npatch = 0;
+    a.csplit = (d->tile_cfg / 100000) % 10;            // 0 = cout tile fastest (one weight slice per XCD)
+    a.ablate = d->tile_cfg / 1000000;                  // honoured by -DTCS_S16_ABLATE builds only
     if (!a.out16 && !a.out32) return TCS_EINVAL;
     if (a.act == TCS_ACT_RELU_ADD_RELU) return TCS_EUNSUPPORTED;
     // the packed weight image pads K to a multiple of 64 channels (tcs_conv_packed_floats_f16x3): nk may not exceed it
     const int kpack = ((d->Cin + 63) / 64) * 4;
-    int kst = d->ksize == 1 ? ((min_k % 4 == 0) ? 4 : 2) : 1;
-    int cfg = d->tile_cfg;
+    int kst = 1;
+    if (d->ksize == 1) {                               // two k-steps per stage when every source has an even number of them
+        kst = 2;
+        for (int i = 0; i < d->n_src; ++i)
+            if (((d->src_ch[i] + 15) / 16) % 2 != 0) kst = 1;
+    }
+    int cfg = d->tile_cfg % 100000;
     if (cfg) kst = (cfg / 10) % 10;
     if (kst != 1 && kst != 2 && kst != 4) return TCS_EINVAL;
     for (int i = 0; i < d->n_src; ++i)
@@ -585,7 +603,11 @@ int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
     if (a.out16 && (a.out16_goff < 0 || a.out16_goff + outG > a.out16_groups)) return TCS_EINVAL;
     if (a.out32 && d->epilogue == TCS_EPI_LINEAR && (d->out_coff < 0 || d->out_coff + d->Cout > d->out_ctot)) return TCS_EINVAL;
     hipStream_t s = tcs_stream(stream);
-    if (!cfg) cfg = s16_heuristic(a, d->ksize, stride, min_k);
+    if (!cfg) {
+        cfg = s16_heuristic(a, d->ksize, stride, kst);
+        a.csplit = cfg / 100000;
+        cfg %= 100000;
+    }
     if (a.nct32 % ((cfg / 1000) % 10) != 0) return TCS_EUNSUPPORTED;          // the cout tile must divide the packed tiles
 
     switch (d->epilogue) {

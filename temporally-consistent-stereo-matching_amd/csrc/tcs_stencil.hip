@@ -3,7 +3,7 @@
 // (core/utils/geo_utils.py:73-132, core/update.py:259-300, core/tc_stereo.py:75-88) and the
 // avg_pool2d / interpolate glue of core/update.py:114-124 with direct stencil kernels.
 // One thread per output pixel; lanes run along x so every load/store is coalesced.
-#include "tcs_common.h"
+#include "tcs_s16.h"
 
 // tc_stereo.py:188-189
 __global__ __launch_bounds__(256) void k_flow_step(float* __restrict__ coords1, const float* __restrict__ delta, int W, int n,
@@ -152,7 +152,8 @@ __global__ __launch_bounds__(256) void k_propagate(const float* __restrict__ gra
 __global__ __launch_bounds__(256) void k_softmax_blend(const float* __restrict__ logits, const float* __restrict__ cand, int cand_ctot,
                                                        const float* __restrict__ disp_q, int W, int HW, float* __restrict__ refined,
                                                        float* __restrict__ delta, float* __restrict__ coords1,
-                                                       float* __restrict__ flow_x, float* __restrict__ flow_x_ch, long long flow_x_ch_bstride) {
+                                                       float* __restrict__ flow_x, float* __restrict__ flow_x_ch, long long flow_x_ch_bstride,
+                                                       _Float16* __restrict__ fx16, int fx16_groups, int fx16_ch, int H) {
     const int b = blockIdx.y;
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= HW) return;
@@ -177,6 +178,13 @@ __global__ __launch_bounds__(256) void k_softmax_blend(const float* __restrict__
     // a copy straight into channel 127 of the motion feature buffer (update.py:126)
     if (flow_x) flow_x[o] = c1 - xf;
     if (flow_x_ch) flow_x_ch[(size_t)b * flow_x_ch_bstride + p] = c1 - xf;
+    if (fx16) {          // ... or into channel fx16_ch of the S16 motion feature tensor (hi and lo halves, 2 bytes each)
+        half2_t hi, lo;
+        s16_split2(c1 - xf, 0.f, hi, lo);
+        _Float16* o16 = fx16 + s16_unit(b, fx16_groups, fx16_ch >> 3, 0, H + 2, W + 2, p / W, p % W) + (fx16_ch & 7);
+        o16[0] = hi[0];
+        o16[(size_t)(H + 2) * (W + 2) * 8] = lo[0];
+    }
 }
 
 // tc_stereo.py:75-88 (factor 4) on flow = -disp, clipped like the returned dict (tc_stereo.py:223-224)
@@ -271,7 +279,20 @@ int tcs_softmax_blend(const float* logits9, const float* cand, int cand_ctot, co
     if (delta_disp && !disp_q) return TCS_EINVAL;
     if (flow_x_ch && flow_x_ch_bstride < (long long)H * W) return TCS_EINVAL;
     hipLaunchKernelGGL(k_softmax_blend, dim3(tcs_cdiv((long long)H * W, 256), B), dim3(256), 0, tcs_stream(stream),
-                       logits9, cand, cand_ctot, disp_q, W, H * W, refined, delta_disp, coords1, flow_x, flow_x_ch, flow_x_ch_bstride);
+                       logits9, cand, cand_ctot, disp_q, W, H * W, refined, delta_disp, coords1, flow_x, flow_x_ch, flow_x_ch_bstride,
+                       (_Float16*)nullptr, 0, 0, H);
+    return tcs_launch_status();
+}
+
+int tcs_softmax_blend_s16(const float* logits9, const float* cand, int cand_ctot, const float* disp_q,
+                          int B, int H, int W, float* refined, float* delta_disp, float* coords1, float* flow_x,
+                          void* flow_x_s16, int flow_x_s16_groups, int flow_x_s16_channel, tcs_stream_t stream) {
+    if (!logits9 || !cand || !refined || cand_ctot < 9 || B <= 0 || B > 65535 || H <= 0 || W <= 0) return TCS_EINVAL;
+    if (delta_disp && !disp_q) return TCS_EINVAL;
+    if (flow_x_s16 && (flow_x_s16_channel < 0 || flow_x_s16_channel >= 8 * flow_x_s16_groups)) return TCS_EINVAL;
+    hipLaunchKernelGGL(k_softmax_blend, dim3(tcs_cdiv((long long)H * W, 256), B), dim3(256), 0, tcs_stream(stream),
+                       logits9, cand, cand_ctot, disp_q, W, H * W, refined, delta_disp, coords1, flow_x, (float*)nullptr, 0LL,
+                       reinterpret_cast<_Float16*>(flow_x_s16), flow_x_s16_groups, flow_x_s16_channel, H);
     return tcs_launch_status();
 }
 
@@ -291,7 +312,7 @@ int tcs_avgpool3s2(const float* x, int B, int C, int H, int W, float* out, tcs_s
     return tcs_launch_status();
 }
 
-int tcs_abi_version(void) { return 1; }
+int tcs_abi_version(void) { return 2; }
 
 const char* tcs_error_string(int code) {
     switch (code) {

@@ -14,7 +14,7 @@ PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libtcs_mi355.so")
-SOURCES = ["tcs_corr.hip", "tcs_warp.hip", "tcs_stencil.hip", "tcs_conv.hip", "tcs_conv_f16.hip", "tcs_conv_s16.hip"]
+SOURCES = ["tcs_corr.hip", "tcs_warp.hip", "tcs_stencil.hip", "tcs_conv.hip", "tcs_conv_f16.hip", "tcs_conv_s16.hip", "tcs_s16_ops.hip"]
 # -amdgpu-kernarg-preload-count: the first 16 kernarg dwords of kernels with scalar parameters arrive in SGPRs at wave
 # launch instead of through an s_load round trip (measured on the latency-bound corr lookup: 2.94 -> 2.81 us per launch)
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function",

@@ -35,6 +35,7 @@ class ConvDesc(C.Structure):
         ("blend_keep_z", c_int),
         ("out", c_fp), ("out_ctot", c_int), ("out_coff", c_int), ("out2", c_fp),
         ("stride", c_int), ("math", c_int), ("weight_unscale", c_f),
+        ("out16", c_fp), ("out16_groups", c_int), ("out16_group_offset", c_int),
     ]
 
 
@@ -96,6 +97,13 @@ SIGNATURES = {
     "tcs_s16_from_f32": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_int, c_fp]),
     "tcs_s16_to_f32": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp]),
     "tcs_conv2d_s16": (c_int, [C.POINTER(ConvS16Desc), c_fp]),
+    "tcs_avgpool3s2_s16": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_fp]),
+    "tcs_resize_bilinear_s16": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_int, c_fp]),
+    "tcs_instance_norm_s16_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
+    "tcs_instance_norm_s16": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_f, c_int, c_fp, c_int, c_fp, c_int, c_fp, c_fp]),
+    "tcs_propagate_disparity_s16": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_int, c_fp]),
+    "tcs_s16_set_channel": (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_int, c_int, c_fp]),
+    "tcs_softmax_blend_s16": (c_int, [c_fp, c_fp, c_int, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp]),
 }
 
 

@@ -416,8 +416,21 @@ def _desc(pc: PackedConv, srcs: Sequence[torch.Tensor]) -> nv.ConvDesc:
 
 
 def conv2d(pc: PackedConv, srcs: Sequence[torch.Tensor], act: str = "none", addend=None, post_scale: float = 1.0,
-           out: Optional[torch.Tensor] = None, out_coff: int = 0, stride: int = 1) -> torch.Tensor:
+           out: Optional[torch.Tensor] = None, out_coff: int = 0, stride: int = 1, out16=None, out16_group_offset: int = 0):
+    """`out16` (a tcs_mi355.s16.S16): write the result in pre-split form for tcs_conv2d_s16 consumers INSTEAD of fp32 NCHW
+    (returns out16); stride 1 only."""
     d = _desc(pc, srcs)
+    if out16 is not None:
+        if stride != 1 or (out16.B, out16.H, out16.W) != (d.B, d.H, d.W):
+            raise ValueError("conv2d: bad `out16`")
+        if addend is not None and tuple(addend.shape) != (d.B, pc.cout, d.H, d.W):
+            raise ValueError("conv2d: bad addend shape")
+        d.stride = 1
+        d.epilogue, d.act, d.post_scale = EPI_LINEAR, ACT[act], float(post_scale)
+        d.addend = nv.ptr(addend, "addend")
+        d.out16, d.out16_groups, d.out16_group_offset = out16.ptr(), out16.G, int(out16_group_offset)
+        nv.check(nv.lib().tcs_conv2d(C.byref(d), nv.stream()), "tcs_conv2d[s16 out]")
+        return out16
     if stride not in (1, 2):
         raise ValueError("stride 1 or 2")
     if stride == 2 and (pc.math != MATH_F16X3 or pc.ksize != 3):

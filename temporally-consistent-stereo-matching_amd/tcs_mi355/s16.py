@@ -81,8 +81,17 @@ class S16Pool:
             self.buffers[k] = buf
         return buf
 
+    def get32(self, key, shape, device) -> torch.Tensor:
+        """A persistent fp32 scratch tensor (e.g. a GRU's update gate).  Like the S16 buffers it is never freed while the
+        model lives: captured HIP graphs hold raw pointers to it, and a freed block could be handed to another tensor."""
+        k = (key, tuple(int(v) for v in shape), "f32", str(device))
+        buf = self.buffers.get(k)
+        if buf is None:
+            buf = self.buffers[k] = torch.empty(*k[1], dtype=torch.float32, device=device)
+        return buf
+
     def bytes(self) -> int:
-        return sum(b.data.numel() * 2 for b in self.buffers.values())
+        return sum((b.data if isinstance(b, S16) else b).numel() * (2 if isinstance(b, S16) else 4) for b in self.buffers.values())
 
 
 def to_s16(x: torch.Tensor, out: Optional[S16] = None, group_offset: int = 0) -> S16:
@@ -211,3 +220,77 @@ def gru_update(pc_q: PackedConv, srcs: Sequence[S16], h: S16, z: torch.Tensor, c
     d.tile_cfg = int(tile_cfg)
     nv.check(nv.lib().tcs_conv2d_s16(C.byref(d), nv.stream()), "tcs_conv2d_s16[gru_q]")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# glue on S16 tensors (csrc/tcs_s16_ops.hip)
+# ---------------------------------------------------------------------------------------------
+def avgpool3s2(x: S16, out: Optional[S16] = None) -> S16:
+    """avg_pool2d(3, stride 2, padding 1) (update.py:114-115)."""
+    Ho, Wo = (x.H - 1) // 2 + 1, (x.W - 1) // 2 + 1
+    out = zeros(x.B, x.C, Ho, Wo, x.device, x.G) if out is None else out
+    if (out.B, out.H, out.W) != (x.B, Ho, Wo) or out.G < x.G:
+        raise ValueError("avgpool3s2: bad `out`")
+    nv.check(nv.lib().tcs_avgpool3s2_s16(x.ptr(), x.B, x.G, x.H, x.W, out.ptr(), out.G, nv.stream()), "tcs_avgpool3s2_s16")
+    return out
+
+
+def resize_bilinear(x: S16, Ho: int, Wo: int, out: Optional[S16] = None) -> S16:
+    """F.interpolate(bilinear, align_corners=True) (update.py:122-124)."""
+    out = zeros(x.B, x.C, Ho, Wo, x.device, x.G) if out is None else out
+    if (out.B, out.H, out.W) != (x.B, Ho, Wo) or out.G < x.G:
+        raise ValueError("resize_bilinear: bad `out`")
+    nv.check(nv.lib().tcs_resize_bilinear_s16(x.ptr(), x.B, x.G, x.H, x.W, int(Ho), int(Wo), out.ptr(), out.G, nv.stream()),
+             "tcs_resize_bilinear_s16")
+    return out
+
+
+_IN_WS: Dict[tuple, torch.Tensor] = {}
+
+
+def instance_norm(x: S16, act: str = "none", addend: Optional[S16] = None, eps: float = 1e-5, out: Optional[S16] = None) -> S16:
+    """act(InstanceNorm2d(x)) + addend on S16 tensors (affine=False, biased variance); `out` may be `x`."""
+    out = zeros(x.B, x.C, x.H, x.W, x.device, x.G) if out is None else out
+    if addend is not None and (addend.B, addend.H, addend.W, addend.G) != (x.B, x.H, x.W, x.G):
+        raise ValueError("instance_norm: bad addend")
+    if (out.B, out.H, out.W, out.G) != (x.B, x.H, x.W, x.G):
+        raise ValueError("instance_norm: bad `out`")
+    L = nv.lib()
+    key = (x.B, x.G, x.H, x.W, str(x.device))
+    ws = _IN_WS.get(key)
+    if ws is None:
+        ws = _IN_WS[key] = torch.empty(L.tcs_instance_norm_s16_workspace_bytes(x.B, x.G, x.H, x.W) // 4, dtype=torch.float32, device=x.device)
+    nv.check(L.tcs_instance_norm_s16(x.ptr(), x.B, x.G, x.H, x.W, float(eps), ACT[act], None if addend is None else addend.ptr(),
+                                     0 if addend is None else addend.G, out.ptr(), out.G, nv.ptr(ws), nv.stream()), "tcs_instance_norm_s16")
+    return out
+
+
+def propagate_disparity(grad: torch.Tensor, disp: torch.Tensor, out16: Optional[S16] = None, cand9: Optional[torch.Tensor] = None):
+    """DispRefine.propagate_disparity (update.py:259-289): -> (S16 with the 27 stem channels, fp32 [B,9,H,W] candidates)."""
+    B, _, H, W = (int(v) for v in disp.shape)
+    out16 = zeros(B, 27, H, W, disp.device) if out16 is None else out16
+    cand9 = torch.empty(B, 9, H, W, dtype=torch.float32, device=disp.device) if cand9 is None else cand9
+    nv.check(nv.lib().tcs_propagate_disparity_s16(nv.ptr(grad, "grad"), nv.ptr(disp, "disp"), B, H, W, nv.ptr(cand9), out16.ptr(), out16.G,
+                                                  nv.stream()), "tcs_propagate_disparity_s16")
+    return out16, cand9
+
+
+def set_channel(x: torch.Tensor, out: S16, channel: int) -> S16:
+    """out[:, channel] = x ([B,1,H,W] fp32)."""
+    B, _, H, W = (int(v) for v in x.shape)
+    nv.check(nv.lib().tcs_s16_set_channel(nv.ptr(x, "x"), B, H, W, out.ptr(), out.G, int(channel), nv.stream()), "tcs_s16_set_channel")
+    return out
+
+
+def softmax_blend(logits9, cand9, disp_q, coords1, flow_x, flow_x_s16: Optional[S16] = None, flow_x_channel: int = 0, refined=None,
+                  delta=None):
+    """DispRefine's 9-way softmax blend (update.py:298-300) + the coordinate bookkeeping of tc_stereo.py:198-202; the next
+    iteration's flow input also goes into channel `flow_x_channel` of `flow_x_s16` (the motion features, update.py:126)."""
+    B, _, H, W = (int(v) for v in logits9.shape)
+    refined = torch.empty(B, 1, H, W, dtype=torch.float32, device=logits9.device) if refined is None else refined
+    delta = torch.empty_like(refined) if delta is None else delta
+    nv.check(nv.lib().tcs_softmax_blend_s16(nv.ptr(logits9, "logits"), nv.ptr(cand9, "cand"), int(cand9.shape[1]), nv.ptr(disp_q), B, H, W,
+                                            nv.ptr(refined), nv.ptr(delta), nv.ptr(coords1), nv.ptr(flow_x),
+                                            None if flow_x_s16 is None else flow_x_s16.ptr(), 0 if flow_x_s16 is None else flow_x_s16.G,
+                                            int(flow_x_channel), nv.stream()), "tcs_softmax_blend_s16")
+    return refined, delta

@@ -1,0 +1,189 @@
+"""GPU parity of the pre-split ("S16") activation path — tcs_conv2d_s16 and its glue kernels — through the C ABI.
+
+The S16 kernels have no counterpart in the reference: they are an internal representation of the same fp32 tensors.
+Each test therefore checks against fp64 PyTorch arithmetic on the CPU (convolutions, pooling, normalisation) at the
+tolerances of the fp32-tensor kernels they replace (tests/test_gpu_parity.py): <= 2e-5 for single convolutions,
+<= 1e-5 for the memory-bound glue.  The blocks built from them are pinned to the reference by the module goldens in
+test_gpu_parity.py (ub_*, dg_*, dr_*, hu_*), which run through these kernels."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import maxdiff
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from tcs_mi355 import native
+    native.lib()
+    return torch.device("cuda:0")
+
+
+def D(x, dev):
+    return x.to(dev).contiguous()
+
+
+def test_s16_roundtrip_and_border(dev):
+    from tcs_mi355 import s16
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 27, 9, 21, generator=gen)
+    x[:, 3] *= 1e-5            # lo halves in fp16-subnormal territory
+    x[:, 4] *= 3e3
+    x[0, 5, 0, 0] = 7e4        # beyond fp16 range: saturates at 65504 (documented domain of the split)
+    t = s16.to_s16(D(x, dev))
+    assert t.G == 4 and tuple(t.data.shape) == (2, 4, 2, 11, 23, 8)
+    back = t.float().cpu()
+    ref = x.clamp(-65504, 65504)
+    # x = hi + lo to 2^-22 relative, with the fp16 subnormal step (2^-24) / 2 as the absolute floor for tiny values
+    assert bool(((back - ref).abs() <= 2.0 ** -22 * ref.abs() + 2.0 ** -25).all())
+    d = t.data.float().cpu()
+    assert float(d[:, :, :, 0].abs().max()) == 0 and float(d[:, :, :, -1].abs().max()) == 0       # zero border rows
+    assert float(d[:, :, :, :, 0].abs().max()) == 0 and float(d[:, :, :, :, -1].abs().max()) == 0  # zero border columns
+    assert float(d[:, 3, :, :, :, 3:].abs().max()) == 0                                             # padding channels 27..31
+    # virtual concat: a second tensor into the upper groups of a wider buffer
+    wide = s16.zeros(2, 64, 9, 21, dev)
+    y = torch.randn(2, 32, 9, 21, generator=gen)
+    s16.to_s16(D(x, dev), out=wide, group_offset=0)
+    s16.to_s16(D(y, dev), out=wide, group_offset=4)
+    assert maxdiff(s16.from_s16(wide, 32, group_offset=4), y) <= 1e-6
+
+
+CONV_CASES = [
+    dict(B=1, cins=(128, 128, 128), cout=256, k=3, H=12, W=40),       # gru08-like, 3 virtual sources
+    dict(B=2, cins=(32, 64, 64), cout=64, k=3, H=9, W=37),            # conv_4_4: mixed source widths, ragged grid, batch 2
+    dict(B=1, cins=(64, 64), cout=127, k=3, H=8, W=24),               # encoder.conv: 127 outputs (masked partial store)
+    dict(B=1, cins=(27,), cout=96, k=1, H=7, W=65),                   # disp_f_stem: 27 inputs
+    dict(B=1, cins=(256,), cout=1, k=3, H=6, W=32),                   # flow head conv2: one output channel
+    dict(B=1, cins=(128,), cout=9, k=1, H=11, W=33),                  # w_head[2]
+    dict(B=1, cins=(128, 64), cout=96, k=3, H=17, W=35),              # odd grid, 96 outputs (3 tiles)
+    dict(B=1, cins=(64,), cout=96, k=3, H=16, W=34, stride=2),        # conv_4_8
+    dict(B=1, cins=(96,), cout=128, k=3, H=15, W=33, stride=2),       # stride 2 on an odd grid
+]
+
+
+@pytest.mark.parametrize("cfg", CONV_CASES)
+def test_conv2d_s16_vs_torch(dev, cfg):
+    from tcs_mi355 import ops, s16
+    gen = torch.Generator().manual_seed(cfg["cout"] + cfg["k"] + cfg["H"])
+    cin, stride = sum(cfg["cins"]), cfg.get("stride", 1)
+    w = torch.randn(cfg["cout"], cin, cfg["k"], cfg["k"], generator=gen) * (2.0 / (cin * cfg["k"] ** 2)) ** 0.5
+    b = torch.randn(cfg["cout"], generator=gen) * 0.1
+    xs = [torch.randn(cfg["B"], c, cfg["H"], cfg["W"], generator=gen) for c in cfg["cins"]]
+    ref = F.conv2d(torch.cat(xs, 1).double(), w.double(), b.double(), padding=cfg["k"] // 2, stride=stride)
+    add = torch.randn(ref.shape, generator=gen)
+    pc = ops.pack_conv(D(w, dev), D(b, dev), "f16x3")
+    xs16 = [s16.to_s16(D(x, dev)) for x in xs]
+    tiles = [0]
+    if cfg["k"] == 3 and stride == 1:
+        tiles += [1412, 1413, 101812, 201412] + ([2412, 102812, 12412] if cfg["cout"] % 64 == 0 else [])
+    elif cfg["k"] == 1:
+        tiles += [1412, 101422] if cin % 32 == 0 else [1412]
+    for tc in tiles:
+        o16, o32 = s16.conv2d(pc, xs16, want32=True, stride=stride, tile_cfg=tc)
+        assert maxdiff(o32, ref) <= 2e-5, tc
+        out = s16.zeros(cfg["B"], cfg["cout"], ref.shape[2], ref.shape[3], dev)
+        s16.conv2d(pc, xs16, act="relu", addend=D(add, dev), post_scale=0.25, out16=out, stride=stride, tile_cfg=tc)
+        assert maxdiff(out.float(), 0.25 * torch.relu(ref + add.double())) <= 2e-5, tc
+    for act, fn in (("leaky", lambda t: F.leaky_relu(t, 0.01)), ("tanh", torch.tanh), ("sigmoid", torch.sigmoid)):
+        assert maxdiff(s16.conv2d(pc, xs16, act=act, stride=stride)[0].float(), fn(ref)) <= 2e-5
+
+
+def test_conv2d_s16_partial_store_keeps_foreign_channel(dev):
+    """encoder.conv writes 127 channels into the 128-channel motion buffer whose channel 127 belongs to the blend kernel."""
+    from tcs_mi355 import ops, s16
+    gen = torch.Generator().manual_seed(3)
+    w = torch.randn(127, 128, 3, 3, generator=gen) * 0.03
+    x = torch.randn(1, 128, 10, 40, generator=gen)
+    flow = torch.randn(1, 1, 10, 40, generator=gen) * 20
+    buf = s16.zeros(1, 128, 10, 40, dev)
+    s16.set_channel(D(flow, dev), buf, 127)
+    s16.conv2d(ops.pack_conv(D(w, dev), None, "f16x3"), [s16.to_s16(D(x, dev))], act="relu", out16=buf)
+    got = buf.float()
+    assert maxdiff(got[:, :127], torch.relu(F.conv2d(x.double(), w.double(), padding=1))) <= 2e-5
+    assert maxdiff(got[:, 127:], flow) <= 2.0 ** -21 * 20 * 4
+
+
+def test_conv2d_s16_from_fp32_sources(dev):
+    """The fp32-input kernels with an S16 epilogue (convc1 36->64 1x1, convf1 1->64 7x7, grad stem 2->32 3x3, fp32-MFMA 32->64)."""
+    from tcs_mi355 import ops, s16
+    gen = torch.Generator().manual_seed(5)
+    for cin, cout, k, math in ((36, 64, 1, "f16x3"), (1, 64, 7, "f16x3"), (1, 64, 1, "f16x3"), (2, 32, 3, "f16x3"), (32, 64, 3, "f32")):
+        w = torch.randn(cout, cin, k, k, generator=gen) * (2.0 / (cin * k * k)) ** 0.5
+        b = torch.randn(cout, generator=gen) * 0.1
+        x = torch.randn(2, cin, 9, 37, generator=gen)
+        out = s16.zeros(2, cout, 9, 37, dev)
+        ops.conv2d(ops.pack_conv(D(w, dev), D(b, dev), math), [D(x, dev)], act="relu", out16=out)
+        assert maxdiff(out.float(), torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=k // 2))) <= 2e-5, (cin, cout, k)
+
+
+def test_gru_s16_vs_torch(dev):
+    """Both GRU epilogues (update.py:77-87 and :26-36) on S16 tensors, in-place state update, 3x3 and 1x1 cells."""
+    from tcs_mi355 import ops, s16
+    gen = torch.Generator().manual_seed(9)
+    for k, keep_z, cx in ((3, False, (128, 128)), (1, True, (64,))):
+        hid, H, W = 128, 10, 37
+        cin = hid + sum(cx)
+        wzr = torch.randn(2 * hid, cin, k, k, generator=gen) * (1.0 / (cin * k * k)) ** 0.5
+        wq = torch.randn(hid, cin, k, k, generator=gen) * (1.0 / (cin * k * k)) ** 0.5
+        bzr, bq = torch.randn(2 * hid, generator=gen) * 0.1, torch.randn(hid, generator=gen) * 0.1
+        h = torch.tanh(torch.randn(1, hid, H, W, generator=gen))
+        xs = [torch.randn(1, c, H, W, generator=gen) for c in cx]
+        cz, cr, cq = (torch.randn(1, hid, H, W, generator=gen) * 0.3 for _ in range(3))
+        hx = torch.cat([h, *xs], 1).double()
+        zr = F.conv2d(hx, wzr.double(), bzr.double(), padding=k // 2)
+        z, r = torch.sigmoid(zr[:, :hid] + cz), torch.sigmoid(zr[:, hid:] + cr)
+        q = torch.tanh(F.conv2d(torch.cat([r * h, *xs], 1).double(), wq.double(), bq.double(), padding=k // 2) + cq)
+        ref = z * h + (1 - z) * q if keep_z else (1 - z) * h + z * q
+        h16, xs16 = s16.to_s16(D(h, dev)), [s16.to_s16(D(x, dev)) for x in xs]
+        zz, rh = s16.gru_gates(ops.pack_conv(D(wzr, dev), D(bzr, dev), "f16x3"), [h16, *xs16], h16, D(cz, dev), D(cr, dev))
+        assert maxdiff(zz, z) <= 1e-5 and maxdiff(rh.float(), r * h) <= 1e-5
+        out = s16.gru_update(ops.pack_conv(D(wq, dev), D(bq, dev), "f16x3"), [rh, *xs16], h16, zz, D(cq, dev), keep_z=keep_z, out=h16)
+        assert out is h16 and maxdiff(h16.float(), ref) <= 1e-5, k
+
+
+def test_deconv_s16_vs_torch(dev):
+    from tcs_mi355 import ops, s16
+    gen = torch.Generator().manual_seed(11)
+    for cin, cout, H, W in ((128, 96, 6, 20), (96, 64, 9, 17)):
+        wt = torch.randn(cin, cout, 4, 4, generator=gen) * (1.0 / (cin * 4)) ** 0.5
+        x = torch.randn(2, cin, H, W, generator=gen)
+        ref = F.conv_transpose2d(x.double(), wt.double(), stride=2, padding=1)
+        got = s16.deconv4x4s2(ops.pack_deconv4x4s2(D(wt, dev)), [s16.to_s16(D(x, dev))])
+        assert (got.H, got.W) == (2 * H, 2 * W) and maxdiff(got.float(), ref) <= 2e-5
+
+
+def test_glue_s16_vs_torch(dev):
+    from tcs_mi355 import ops, s16
+    gen = torch.Generator().manual_seed(13)
+    x = torch.randn(2, 24, 13, 17, generator=gen)
+    x16 = s16.to_s16(D(x, dev))
+    assert maxdiff(s16.avgpool3s2(x16).float(), F.avg_pool2d(x, 3, stride=2, padding=1)) <= 1e-6
+    assert maxdiff(s16.resize_bilinear(x16, 26, 34).float(), F.interpolate(x, (26, 34), mode="bilinear", align_corners=True)) <= 1e-5
+    # InstanceNorm + LeakyReLU + skip at the two shapes of the loop's up-blocks (one / several plane slices)
+    for C_, H, W in ((96, 12, 20), (64, 120, 160)):
+        y = torch.randn(1, C_, H, W, generator=gen) * 3 + 1.5
+        rem = torch.randn(1, C_, H, W, generator=gen)
+        ref = F.leaky_relu(F.instance_norm(y.double(), eps=1e-5), 0.01) + rem.double()
+        y16 = s16.to_s16(D(y, dev))
+        got = s16.instance_norm(y16, act="leaky", addend=s16.to_s16(D(rem, dev)), out=y16)
+        assert got is y16 and maxdiff(y16.float(), ref) <= 1e-5, (C_, H, W)
+        assert maxdiff(s16.instance_norm(s16.to_s16(D(y, dev))).float(), F.instance_norm(y.double(), eps=1e-5)) <= 1e-5
+    # candidate stencil: the S16 stem input and the fp32 candidates against the fp32 kernel (golden-pinned in test_gpu_parity)
+    g, d = torch.randn(2, 2, 9, 21, generator=gen), torch.rand(2, 1, 9, 21, generator=gen) * 40
+    f27 = ops.propagate_disparity(D(g, dev), D(d, dev))
+    o16, c9 = s16.propagate_disparity(D(g, dev), D(d, dev))
+    assert o16.G == 4 and maxdiff(o16.float(), f27) <= 2.0 ** -21 * 64 and maxdiff(c9, f27[:, :9]) == 0
+    # blend: identical fp32 outputs to the fp32 entry point, plus the flow channel in the S16 buffer
+    logits = torch.randn(2, 9, 9, 21, generator=gen)
+    co, fx = torch.empty(2, 1, 9, 21, device=dev), torch.empty(2, 1, 9, 21, device=dev)
+    ref_r, ref_d = ops.softmax_blend(D(logits, dev), f27, disp_q=D(d, dev), want_delta=True)
+    buf = s16.zeros(2, 128, 9, 21, dev)
+    r, dl = s16.softmax_blend(D(logits, dev), c9, D(d, dev), co, fx, flow_x_s16=buf, flow_x_channel=127)
+    assert maxdiff(r, ref_r) == 0 and maxdiff(dl, ref_d) == 0
+    xs = torch.arange(21, dtype=torch.float32).view(1, 1, 1, 21)
+    assert maxdiff(co, xs - r.cpu()) <= 1e-6 and maxdiff(fx, co.cpu() - xs) <= 1e-5
+    assert maxdiff(s16.from_s16(buf, 128)[:, 127:], fx) <= 2.0 ** -21 * 64
+    assert float(s16.from_s16(buf, 128)[:, :127].abs().max()) == 0

@@ -33,8 +33,8 @@ SHAPES = [  # name, (cins...), cout, k, H, W, epilogue, stride
     ("s2 64->96", (64,), 96, 3, 120, 160, "lin", 2),
     ("deconv 128->96", (128,), 96, 3, 30, 40, "deconv", 1),
 ]
-CFGS3 = [1412, 1512, 2512, 1812, 2812, 11412, 11413, 12412, 12413, 12414, 12512, 12513, 11513, 12812, 12813, 14412, 14413]
-CFGS1 = [1422, 1423, 2422, 2423, 1442, 1443, 2442, 2443]
+CFGS3 = [1412, 101412, 201412, 401412, 1812, 101812, 201812, 401812, 2512, 102512, 202512, 2412, 102412, 2812, 102812, 202812, 112412, 212412, 112512]
+CFGS1 = [1422, 101422, 2422, 102422, 202422, 1442, 2442, 102442]
 only = sys.argv[1] if len(sys.argv) > 1 else ""
 forced = [int(c) for c in os.environ.get("CFGS", "").split(",") if c]
 gen = torch.Generator().manual_seed(0)
