@@ -191,24 +191,42 @@ class TCStereo(nn.Module):
         motion = pool.get(("frame", "motion"), coords1.shape[0], 128, coords1.shape[2], coords1.shape[3], coords1.device)
         s16.set_channel(flows_x, motion, 127)
         ub = self.update_block
+        from tcs_mi355.streams import fork_join
+        hu_delta = None              # the hidden-state update of iteration i-1 runs at the head of iteration i's coarse branch
         for itr in range(iters):
-            corr = corr_fn(coords1)
-            if n3 and a.slow_fast_gru:
-                ub.run(pool, nets, inp_list, None, None, None, iter32=True, iter16=False, iter08=False, update=False)
-            if a.n_gru_layers >= 2 and a.slow_fast_gru:
-                ub.run(pool, nets, inp_list, None, None, None, iter32=n3, iter16=True, iter08=False, update=False)
-            delta_flow = ub.run(pool, nets, inp_list, corr, flows_x, motion, iter32=n3, iter16=a.n_gru_layers >= 2)
+            # Two independent chains open an iteration: [hidden-state update of the previous iteration -> gru32 -> gru16 ->
+            # interp] needs only the hidden states; [corr lookup -> motion encoder] needs only coords1 / the flow written by the
+            # previous blend.  They run as parallel branches (streams.py); gru08 joins them.
+            def enc_branch():
+                corr = corr_fn(coords1)
+                return corr, ub.encoder.run(pool, flows_x, corr, motion)
+
+            def coarse_branch():
+                if hu_delta is not None:
+                    self.hiddenstate_update.run(pool, nets[0], hu_delta)
+                if n3 and a.slow_fast_gru:
+                    ub.run_coarse(pool, nets, inp_list, iter16=False, iter32=True, want_up16=False)
+                if a.n_gru_layers >= 2 and a.slow_fast_gru:
+                    ub.run_coarse(pool, nets, inp_list, iter16=True, iter32=n3, want_up16=False)
+                return ub.run_coarse(pool, nets, inp_list, iter16=a.n_gru_layers >= 2, iter32=n3)
+
+            (corr, m), up16 = fork_join([enc_branch, coarse_branch], site="iter")
+            delta_flow = ub.run_fine(pool, nets, inp_list, m, up16)
             # disp_q = x - (coords1 + delta), 5 * disp2disp_gradient_xy (update.py:199) and the gradient candidates in one
             # launch; coords1 is replaced by the blend kernel's output below
             disp_q, g5, cands = ops.flow_step_grads(coords1, delta_flow, scale=5.0)
             disp_grad, context = self.disp_grad_refine.run(pool, g5, cands, grads16)
             last = itr == iters - 1
             refined, up_mask, fused = self.disp_refine.run(pool, disp_grad, disp_q, nets[0], context, want_mask=last, motion=motion)
-            self.hiddenstate_update.run(pool, nets[0], fused["delta_disp"])
+            hu_delta = fused["delta_disp"]
             coords1, flows_x = fused["coords1"], fused["flow_x"]
             if trace is not None:
+                self.hiddenstate_update.run(pool, nets[0], hu_delta)       # debugging hook: states as of the end of the iteration
+                hu_delta = None
                 trace["iters"].append(dict(corr=corr, delta=delta_flow, disp_q=disp_q, refined=refined,
                                            net=[t.float() for t in nets]))
+        if hu_delta is not None:
+            self.hiddenstate_update.run(pool, nets[0], hu_delta)
         net_list = [t.float() for t in nets]
 
         flow_up, flow_q = ops.convex_upsample(refined.contiguous(), up_mask)

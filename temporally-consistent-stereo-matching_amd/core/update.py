@@ -337,36 +337,39 @@ class BasicMultiUpdateBlock(nn.Module):
             motion_out.copy_(motion.float())
         return (out, res) if update else out
 
+    def run_coarse(self, pool, net, inp, iter16=True, iter32=True, want_up16=True):
+        """gru32 -> gru16 (update.py:147-153) on S16 states, in place; returns interp(net16 -> 1/4 grid) for gru08 (or None).
+        Independent of the motion encoder, which only feeds gru08."""
+        n = self.args.n_gru_layers
+        if iter32:
+            p = s16.avgpool3s2(net[1], out=pool.get((id(self), "pool16"), net[2].B, net[1].C, net[2].H, net[2].W, net[2].device))
+            self.gru32.step16(pool, net[2], [p], *inp[2])
+        if iter16:
+            xs = [s16.avgpool3s2(net[0], out=pool.get((id(self), "pool08"), net[1].B, net[0].C, net[1].H, net[1].W, net[1].device))]
+            if n > 2:
+                xs.append(s16.resize_bilinear(net[2], net[1].H, net[1].W,
+                                              out=pool.get((id(self), "up32"), net[1].B, net[2].C, net[1].H, net[1].W, net[1].device)))
+            self.gru16.step16(pool, net[1], xs, *inp[1])
+        if want_up16 and n > 1:
+            return s16.resize_bilinear(net[1], net[0].H, net[0].W,
+                                       out=pool.get((id(self), "up16"), net[0].B, net[1].C, net[0].H, net[0].W, net[0].device))
+        return None
+
+    def run_fine(self, pool, net, inp, motion_features, up16, update=True):
+        """gru08 on (motion features, upsampled net16) and the flow head (update.py:154-168); returns delta_flow (fp32)."""
+        self.gru08.step16(pool, net[0], [motion_features] + ([up16] if up16 is not None else []), *inp[0])
+        return self.flow_head.run(pool, net[0]) if update else None
+
     def run(self, pool, net, inp, corr, flow, motion, iter08=True, iter16=True, iter32=True, update=True):
         """`net`: list of S16 hidden states, updated IN PLACE; `inp`: per scale (cz, cr, cq) fp32; returns delta_flow (fp32)
         when `update`."""
-        n = self.args.n_gru_layers
-
-        def coarse():            # gru32 -> gru16: independent of the motion encoder (which only feeds gru08)
-            if iter32:
-                p = s16.avgpool3s2(net[1], out=pool.get((id(self), "pool16"), net[2].B, net[1].C, net[2].H, net[2].W, net[2].device))
-                self.gru32.step16(pool, net[2], [p], *inp[2])
-            if iter16:
-                xs = [s16.avgpool3s2(net[0], out=pool.get((id(self), "pool08"), net[1].B, net[0].C, net[1].H, net[1].W, net[1].device))]
-                if n > 2:
-                    xs.append(s16.resize_bilinear(net[2], net[1].H, net[1].W,
-                                                  out=pool.get((id(self), "up32"), net[1].B, net[2].C, net[1].H, net[1].W, net[1].device)))
-                self.gru16.step16(pool, net[1], xs, *inp[1])
-            if iter08 and n > 1:
-                return s16.resize_bilinear(net[1], net[0].H, net[0].W,
-                                           out=pool.get((id(self), "up16"), net[0].B, net[1].C, net[0].H, net[0].W, net[0].device))
+        if not iter08:
+            self.run_coarse(pool, net, inp, iter16, iter32, want_up16=False)
             return None
-
-        if iter08:
-            # the encoder (which forks again) stays on the current stream: ROCm 7.2 segfaults in hipStreamEndCapture when
-            # a side branch of a captured fork forks a second time
-            m, up16 = fork_join([lambda: self.encoder.run(pool, flow, corr, motion), coarse], site="coarse")
-            self.gru08.step16(pool, net[0], [m] + ([up16] if n > 1 else []), *inp[0])
-        else:
-            coarse()
-        if not update:
-            return None
-        return self.flow_head.run(pool, net[0])
+        # encoder on the origin stream (it forks again), coarse GRUs on a side stream
+        m, up16 = fork_join([lambda: self.encoder.run(pool, flow, corr, motion),
+                             lambda: self.run_coarse(pool, net, inp, iter16, iter32)], site="coarse")
+        return self.run_fine(pool, net, inp, m, up16, update)
 
 
 # ---------------------------------------------------------------------------------------------

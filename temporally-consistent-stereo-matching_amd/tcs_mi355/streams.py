@@ -5,10 +5,11 @@ motion encoder and the coarse GRUs; the two stems of the gradient predictor; its
 candidate branch of DispRefine).  Each of those kernels fills only part of the 256 CUs, so running the chains
 side by side raises occupancy.  Under HIP-graph capture the fork/join becomes parallel branches of the graph.
 
-OFF by default (+1 % measured).  Enable with TCS_MI355_STREAMS=1.  On ROCm 7.2 `hipStreamEndCapture` segfaults when a
-SIDE branch of a captured fork forks again (tools/repro_fork_capture.py), so while a capture is in progress a nested
-fork runs its branches serially on the stream it is on instead of forking; top-level forks are captured as parallel
-graph branches.
+ON by default (TCS_MI355_STREAMS=0 disables): with the loop's kernels at 150-600 workgroups, overlapping the motion encoder
+with the hidden-state update and the coarse GRUs is worth ~1.5 ms of a 32 ms frame.  On ROCm 7.2 `hipStreamEndCapture`
+segfaults when a SIDE branch of a captured fork forks again (tools/repro_fork_capture.py), so a fork requested from
+inside a side branch runs its branches serially on that side stream; forks nested on the ORIGIN stream are captured as
+parallel graph branches.
 """
 from __future__ import annotations
 
@@ -17,11 +18,12 @@ from typing import Callable, List, Sequence
 
 import torch
 
-ENABLED = os.environ.get("TCS_MI355_STREAMS", "0") == "1"
+ENABLED = os.environ.get("TCS_MI355_STREAMS", "1") == "1"
 SITES = os.environ.get("TCS_MI355_FORK_SITES", "all").split(",")       # diagnostic: restrict forking to named call sites
 _POOL: dict = {}
 _DEPTH = 0          # nesting level of fork_join: each level owns its own side streams (a nested fork must never
                     # pick the stream it is already running on)
+_IN_SIDE = 0        # > 0 while a side branch is being enqueued
 
 
 def _side_streams(device, depth: int, n: int) -> List[torch.cuda.Stream]:
@@ -37,9 +39,9 @@ def fork_join(fns: Sequence[Callable[[], object]], site: str = "") -> list:
     every side chain before continuing, so memory handed between the chains is ordered."""
     if not ENABLED or len(fns) <= 1 or not torch.cuda.is_available() or ("all" not in SITES and site not in SITES):
         return [f() for f in fns]
-    global _DEPTH
-    if _DEPTH > 0 and torch.cuda.is_current_stream_capturing():
-        return [f() for f in fns]          # nested fork under capture: serial (ROCm 7.2 hipStreamEndCapture crash, see above)
+    global _DEPTH, _IN_SIDE
+    if _IN_SIDE > 0:
+        return [f() for f in fns]          # a side branch never forks again (ROCm 7.2 hipStreamEndCapture crash, see above)
     cur = torch.cuda.current_stream()
     sides = _side_streams(cur.device, _DEPTH, len(fns) - 1)
     results = [None] * len(fns)
@@ -47,8 +49,12 @@ def fork_join(fns: Sequence[Callable[[], object]], site: str = "") -> list:
     try:
         for i, st in enumerate(sides, start=1):
             st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                results[i] = fns[i]()
+            _IN_SIDE += 1
+            try:
+                with torch.cuda.stream(st):
+                    results[i] = fns[i]()
+            finally:
+                _IN_SIDE -= 1
         results[0] = fns[0]()
     finally:
         _DEPTH -= 1
