@@ -17,8 +17,9 @@
 // clamped (valid, finite) positions and never store those pixels (MFMA columns are independent).
 //
 // Tiling: block = ROWS waves, wave = one output row of 32 pixels x 32*MT output channels (D: pixel on the lane).
-// K loop over stages of KSTEPS 16-channel k-steps x all taps; NSTAGE LDS buffers:
-//     wait own DMA pieces of stage s (counted vmcnt) -> s_barrier -> issue DMA of stage s+NSTAGE-1 -> MFMAs of stage s
+// K loop over stages of KSTEPS 16-channel k-steps x all taps; NSTAGE LDS buffers, all filled by the prologue:
+//     wait own DMA pieces of stage s (counted vmcnt) -> s_barrier -> refill the buffer of stage s-1 with stage s+NSTAGE-1
+//     -> MFMAs of stage s
 // i.e. ONE barrier per stage and NSTAGE-1 stages of prefetch in flight across it.  Operand fetches are inline-asm
 // ds_read_b128 with counted lgkmcnt (hipcc would put vmcnt(0) in front of every LDS read that may alias a DMA).
 // Weights: the f16x3 packed image of tcs_pack_conv_weight_f16x3, unchanged.
@@ -235,7 +236,11 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p) {
 #ifdef TCS_S16_ABLATE
 #define S16_ABL_DMA(IS_INPUT) (!(a.ablate & ((IS_INPUT) ? 1 : 2)))
 #define S16_ABL_COMPUTE (!(a.ablate & 4))
+// per-workgroup phase stamps of the diagnostic build (100 MHz device clock): [start, first stage landed, K loop done, end]
+__device__ unsigned long long tcs_s16_stamps[4 * 8192];
+#define S16_STAMP(I) { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 8192) tcs_s16_stamps[4 * blockIdx.x + (I)] = __builtin_amdgcn_s_memrealtime(); }
 #else
+#define S16_STAMP(I) {}
 #define S16_ABL_DMA(IS_INPUT) true
 #define S16_ABL_COMPUTE true
 #endif
@@ -253,6 +258,7 @@ __global__ __launch_bounds__(64 * ROWS) void k_conv_s16(S16Args a) {
     static_assert(R <= 15, "lgkmcnt field");
     static_assert(STAGE_BYTES <= 65536, "ds_read immediate offsets are 16 bits");
 
+    S16_STAMP(0)
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int ct, patch;
@@ -340,22 +346,25 @@ __global__ __launch_bounds__(64 * ROWS) void k_conv_s16(S16Args a) {
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_hi[m], F.b_hi, acc[m], 0, 0, 0);                          \
     }
 
-    // ---- prologue: NSTAGE-1 stages in flight ---------------------------------------------------------------------------
+    // ---- prologue: every buffer is free, so NSTAGE stages go in flight at once ------------------------------------------
 #pragma unroll
-    for (int s = 0; s < NSTAGE - 1; ++s)
+    for (int s = 0; s < NSTAGE; ++s)
         if (s < nstage_total) S16_ISSUE(s, s)
 
     int buf = 0;                                                    // buffer of the stage being multiplied
     for (int s = 0; s < nstage_total; ++s) {
-        // own pieces of stage s have landed: all but the stages issued after it (each PPW pieces) may still be in flight
-        const int newer = min(nstage_total - 1 - s, NSTAGE - 2);
-        if (NSTAGE >= 3 && newer == NSTAGE - 2) { asm volatile("s_waitcnt vmcnt(%0)" :: "i"((NSTAGE - 2) * PPW) : "memory"); }
-        else if (NSTAGE >= 4 && newer == NSTAGE - 3) { asm volatile("s_waitcnt vmcnt(%0)" :: "i"((NSTAGE >= 4 ? NSTAGE - 3 : 0) * PPW) : "memory"); }
+        // own pieces of stage s have landed; the `newer` stages issued after it (PPW pieces each) may stay in flight:
+        // stages 1 .. NSTAGE-1 of the prologue at s = 0, afterwards what iteration s-1 issued (stage s + NSTAGE - 2)
+        const int newer = s == 0 ? min(nstage_total - 1, NSTAGE - 1) : min(nstage_total - 1 - s, NSTAGE - 2);
+        static_assert((NSTAGE - 1) * PPW <= 63, "vmcnt field");
+        if (NSTAGE >= 4 && newer == 3) { asm volatile("s_waitcnt vmcnt(%0)" :: "i"((NSTAGE >= 4 ? 3 : 0) * PPW) : "memory"); }
+        else if (NSTAGE >= 3 && newer == 2) { asm volatile("s_waitcnt vmcnt(%0)" :: "i"((NSTAGE >= 3 ? 2 : 0) * PPW) : "memory"); }
+        else if (newer == 1) { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(PPW) : "memory"); }
         else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         __builtin_amdgcn_s_barrier();                               // everyone's pieces landed; everyone is done with stage s-1
-        if (s + NSTAGE - 1 < nstage_total) {
-            int nb = buf + NSTAGE - 1;
-            nb = nb >= NSTAGE ? nb - NSTAGE : nb;
+        if (s == 0) { S16_STAMP(1) }
+        if (NSTAGE >= 2 && s >= 1 && s + NSTAGE - 1 < nstage_total) {   // refill the buffer that stage s-1 was multiplied from
+            const int nb = buf == 0 ? NSTAGE - 1 : buf - 1;
             S16_ISSUE(nb, s + NSTAGE - 1)
         }
         if (S16_ABL_COMPUTE) {
@@ -372,16 +381,28 @@ __global__ __launch_bounds__(64 * ROWS) void k_conv_s16(S16Args a) {
                 }
             }
         }
+        if (NSTAGE == 1 && s + 1 < nstage_total) {
+            // single buffer (small LDS footprint: up to five workgroups per CU hide each other's fills): everyone is done
+            // reading before the next stage overwrites it
+            __builtin_amdgcn_s_barrier();
+            S16_ISSUE(0, s + 1)
+        }
         buf = buf + 1 == NSTAGE ? 0 : buf + 1;
     }
 #undef S16_ISSUE
 #undef S16_FETCH
 #undef S16_MMA
+    S16_STAMP(2)
 
     const int px = x0 + l31, py = y0 + wave;
-    if (px >= a.W || py >= a.H) return;
+    if (px < a.W && py < a.H) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) s16_epilogue_tile<EPI>(a, b, (ct * MT + m) * 32 + 4 * half, py, px, acc[m]);
+        for (int m = 0; m < MT; ++m) s16_epilogue_tile<EPI>(a, b, (ct * MT + m) * 32 + 4 * half, py, px, acc[m]);
+    }
+#ifdef TCS_S16_ABLATE
+    __builtin_amdgcn_s_waitcnt(0);                                  // stores acknowledged
+    S16_STAMP(3)
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -466,6 +487,7 @@ static int launch_s16_cfg(S16Args& a, int cfg, hipStream_t s) {
     case (10000 + MT_ * 1000 + ROWS_ * 100 + KST_ * 10 + NST_): return launch_s16<KS, MT_, ROWS_, KST_, NST_, STRIDE, EPI, 1>(a, s);
     if constexpr (KS == 3 && STRIDE == 1) {
         switch (cfg) {
+            S16_CASE(1, 4, 1, 1) S16_CASE(2, 4, 1, 1) S16_CASE(1, 8, 1, 1)
             S16_CASE(1, 4, 1, 2) S16_CASE(1, 4, 1, 3) S16_CASE(2, 4, 1, 2) S16_CASE(2, 4, 1, 3)
             S16_CASE(1, 5, 1, 2) S16_CASE(2, 5, 1, 2)
             S16_CASE(1, 8, 1, 2) S16_CASE(2, 8, 1, 2)
@@ -490,10 +512,8 @@ static int launch_s16_cfg(S16Args& a, int cfg, hipStream_t s) {
 }
 
 // Tile choice by grid size, from the layer sweep of tools/bench_conv_s16.py on MI355X (gpurun_out/r2_s16_c.log):
-//  * 3x3 on grids that give >= 180 workgroups with 8-row patches: ROWS = 8, two stages (8 waves share one weight image; 80 KiB
-//    of LDS, so two workgroups per CU); the 64-channel tile only for Cout = 128 layers with >= 192 input channels
-//    (gru08.q 72 -> 59 us, 192->128 35.6 -> 34.4 us), where it halves an otherwise 1.2-per-CU grid;
-//  * smaller grids (1/8 scale with 128 outputs, 1/16 scale, transposed convs): 4-row patches, 32-channel tiles;
+//  * 3x3 on grids that give >= 180 workgroups with 8-row patches: see the branches below (gpurun_out/r2_s16_f.log);
+//  * smaller grids (1/8 scale with 128 outputs, 1/16 scale, transposed convs): 4-row patches, 32-channel tiles, two stages;
 //  * 1x1: two k-steps per stage; 64-channel tiles for Cout >= 256;
 //  * CSPLIT = 1 (all cout tiles of a patch on one XCD, s16_block_tile): 0-3 % on 3x3, 20-30 % on the 1x1 layers.
 static int s16_heuristic(const S16Args& a, int ksize, int stride, int kst1x1) {
@@ -503,10 +523,14 @@ static int s16_heuristic(const S16Args& a, int ksize, int stride, int kst1x1) {
     }
     if (stride == 2) return 1412;
     const long long blocks8 = (long long)tcs_cdiv(a.W, 32) * tcs_cdiv(a.H, 8) * a.B * a.nct32;
-    if (blocks8 >= 180) {
-        const int mt = (a.nct32 == 4 && a.nk >= 12 && blocks8 >= 280) ? 2 : 1;
-        return 100000 + mt * 1000 + 800 + 10 + 2;
+    if (blocks8 >= 280) {
+        // 1/4-scale grids: the long, wide layers (gru08.zr) keep 8-row patches with two stages; everything else runs as 4-row
+        // patches with ONE 31 KiB stage, so that up to five workgroups per CU cover each other's fills (128->128: 25.4 -> 23.8 us,
+        // 192->128: 33.4 -> 31.7 us, gru08.q 69.5 -> 58.7 us)
+        if (a.nct32 >= 8 && a.nk >= 16) return 100000 + 1000 + 800 + 10 + 2;
+        return 100000 + 1000 + 400 + 10 + 1;
     }
+    if (blocks8 >= 180) return 100000 + 1000 + 800 + 10 + 2;
     return 100000 + 1000 + 400 + 10 + 2;
 }
 

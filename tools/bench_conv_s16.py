@@ -33,7 +33,7 @@ SHAPES = [  # name, (cins...), cout, k, H, W, epilogue, stride
     ("s2 64->96", (64,), 96, 3, 120, 160, "lin", 2),
     ("deconv 128->96", (128,), 96, 3, 30, 40, "deconv", 1),
 ]
-CFGS3 = [1412, 101412, 201412, 401412, 1812, 101812, 201812, 401812, 2512, 102512, 202512, 2412, 102412, 2812, 102812, 202812, 112412, 212412, 112512]
+CFGS3 = [101412, 101812, 101411, 102411, 101811, 102812, 102512]
 CFGS1 = [1422, 101422, 2422, 102422, 202422, 1442, 2442, 102442]
 only = sys.argv[1] if len(sys.argv) > 1 else ""
 forced = [int(c) for c in os.environ.get("CFGS", "").split(",") if c]

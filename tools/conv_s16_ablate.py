@@ -22,8 +22,9 @@ import torch
 from tcs_mi355 import ops, s16
 dev = torch.device("cuda:0")
 gen = torch.Generator().manual_seed(0)
-SH = [("gru08.zr", (128, 128, 128), 256, 3, 120, 160), ("conv128->128", (128,), 128, 3, 120, 160), ("gru16.zr", (128, 128, 128), 256, 3, 60, 80)]
-cfgs = [int(c) for c in sys.argv[1:]] or [1412, 2412, 1812, 1413]
+SH = [("gru08.zr", (128, 128, 128), 256, 3, 120, 160), ("conv128->128", (128,), 128, 3, 120, 160), ("conv64->64", (64,), 64, 3, 120, 160),
+      ("gru16.zr", (128, 128, 128), 256, 3, 60, 80)]
+cfgs = [int(c) for c in sys.argv[1:] if not c.startswith("-")] or [1412, 2412, 1812, 1413]
 
 
 def timed(run, n=100, reps=3):
@@ -55,3 +56,24 @@ for name, cins, cout, k, H, W in SH:
             t = timed(lambda: s16.conv2d(pc, xs16, act="relu", out16=out, tile_cfg=cfg + 1000000 * abl))
             line += f"  {tag} {t:6.1f}"
         print(line, flush=True)
+        if "--stamps" in os.environ.get("ABL_FLAGS", ""):
+            import ctypes, numpy as np
+            from tcs_mi355 import native
+            L = native.lib()
+            s16.conv2d(pc, xs16, act="relu", out16=out, tile_cfg=cfg)
+            torch.cuda.synchronize()
+            L.tcs_debug_clear_s16_stamps()
+            for rep_ in range(3):
+                s16.conv2d(pc, xs16, act="relu", out16=out, tile_cfg=cfg)
+                torch.cuda.synchronize()
+            nb = 4096
+            buf = (ctypes.c_ulonglong * (4 * nb))()
+            L.tcs_debug_read_s16_stamps.restype = ctypes.c_int
+            assert L.tcs_debug_read_s16_stamps(buf, nb) == 0
+            st = np.frombuffer(buf, dtype=np.uint64).reshape(nb, 4).astype(np.int64)
+            st = st[st[:, 3] > 0]
+            t0 = st[:, 0].min()
+            rel = (st - t0) * 0.01
+            print(f"    stamps ({len(st)} blocks, us since first block start): start max {rel[:,0].max():.2f} | first-stage-landed avg {rel[:,1].mean():.2f} max {rel[:,1].max():.2f}"
+                  f" | loop-done avg {rel[:,2].mean():.2f} max {rel[:,2].max():.2f} | end avg {rel[:,3].mean():.2f} max {rel[:,3].max():.2f}"
+                  f" | per-block: fill {(rel[:,1]-rel[:,0]).mean():.2f} loop {(rel[:,2]-rel[:,1]).mean():.2f} epilogue {(rel[:,3]-rel[:,2]).mean():.2f}", flush=True)
