@@ -119,12 +119,21 @@ def lookup_burst_us(dev, B, n=200, reps=5):
     coords = (xs - disp).contiguous().to(dev)
     out = ops.corr_lookup(pyr, coords, 4)
     torch.cuda.synchronize()
-    g, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
-    with torch.cuda.stream(side):
-        with torch.cuda.graph(g, stream=side):
-            for _ in range(n):
-                ops.corr_lookup(pyr, coords, 4, out=out)
+    # every launch of the burst also stamps the device clock (first instruction of the first workgroup -> last acknowledged
+    # store of the last one): the kernel's own span with the pyramid hot in L2 / Infinity Cache
+    saved, probe = ops.LOOKUP_PROBE, ops.LookupProbe(dev, slots=n)
+    ops.LOOKUP_PROBE = probe
+    try:
+        g, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(n):
+                    ops.corr_lookup(pyr, coords, 4, out=out)
+    finally:
+        ops.LOOKUP_PROBE = saved
     g.replay()
+    torch.cuda.synchronize()
+    probe.reset()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -132,15 +141,17 @@ def lookup_burst_us(dev, B, n=200, reps=5):
         g.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / (n * reps)
+    hot = probe.durations_us()
+    return e0.elapsed_time(e1) * 1e3 / (n * reps), (float(np.median(hot)) if hot else None)
 
 
-def lookup_roofline(probe, snapshots, burst_us, pixels):
+def lookup_roofline(probe, snapshots, burst, pixels):
     """`roofline` object for the corr lookup.  `achieved` / `frac` use the HIP-event duration (`lookup_burst_us`), which is
     the launch-to-launch interval a stream of dependent kernels really pays and agrees with rocprofv3's kernel trace.
     The in-kernel device-clock interval (first instruction of the first workgroup to the last acknowledged store of the
     last one, s_memrealtime at 100 MHz, every lookup launch of the timed region) is reported next to it: the difference
     is dispatch/completion overhead, not data movement."""
+    burst_us, hot_us = burst
     durs = []
     for snap in snapshots:
         durs += probe.durations_us(snap)
@@ -156,17 +167,29 @@ def lookup_roofline(probe, snapshots, burst_us, pixels):
                              "achieved": round(alg_bytes / (dur_us * 1e-6) / 1e9, 1),
                              "frac": round(alg_bytes / (dur_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                              "timer": "in-kernel s_memrealtime stamps (100 MHz), every lookup launch of the timed region"}
-    # PMC traffic and rocprofv3's own duration come from the committed profile of this same command (profiles/README.md):
-    # bench.py cannot run the profiler on itself.
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_lookup_pmc.json")) as f:
-            pmc = json.load(f)
-        if pmc.get("algorithmic_bytes_per_launch") == alg_bytes:
-            roof["traffic"] = pmc["traffic_bytes_per_launch"]
-            roof["traffic_source"] = "profiles/r01_lookup_pmc.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc passes)"
-            roof["rocprof_avg_launch_us"] = pmc["rocprof_kernel_trace_avg_us"]
-    except (OSError, KeyError, ValueError):
-        pass
+    if hot_us:
+        roof["in_kernel_hot"] = {"median_launch_us": round(hot_us, 3), "achieved": round(alg_bytes / (hot_us * 1e-6) / 1e9, 1),
+                                 "frac": round(alg_bytes / (hot_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "timer": "in-kernel stamps of the burst launches (pyramid and coordinates cache-hot)"}
+    # PMC traffic and rocprofv3's own durations come from the committed profile of this same command (profiles/README.md):
+    # bench.py cannot run the profiler on itself.  rocprofv3's per-kernel interval includes ~2 us of dispatch / completion
+    # (trivial kernels read 4.5-5 us in the same trace), so frac_rocprof is a lower bound of the kernel's own rate.
+    for name in ("r02_lookup_pmc.json", "r01_lookup_pmc.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                pmc = json.load(f)
+            if pmc.get("algorithmic_bytes_per_launch") == alg_bytes:
+                roof["traffic"] = pmc["traffic_bytes_per_launch"]
+                roof["traffic_source"] = f"profiles/{name} (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc passes)"
+                for key in ("rocprof_burst_avg_us", "rocprof_loop_avg_us", "rocprof_kernel_trace_avg_us"):
+                    if key in pmc:
+                        roof[key] = pmc[key]
+                rp = pmc.get("rocprof_burst_avg_us") or pmc.get("rocprof_kernel_trace_avg_us")
+                if rp:
+                    roof["frac_rocprof"] = round(alg_bytes / (rp * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                break
+        except (OSError, KeyError, ValueError):
+            continue
     return roof
 
 

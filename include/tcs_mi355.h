@@ -337,6 +337,17 @@ int tcs_softmax_blend_s16(const float* logits9, const float* cand, int cand_ctot
                           int B, int H, int W, float* refined, float* delta_disp, float* coords1, float* flow_x,
                           void* flow_x_s16, int flow_x_s16_groups, int flow_x_s16_channel, tcs_stream_t stream);
 
+/* HiddenstateUpdater.forward (core/update.py:57-68) as one launch: x = W2.LeakyReLU(w1*delta + b1) + b2; z,r = sigmoid(Wzr.[h,x] + bzr);
+ * q = tanh(Wq.[r*h,x] + bq); h <- z*h + (1-z)*q, in place on the S16 hidden state (128 channels).  The three 1x1 weight
+ * matrices are A-fragment images from tcs_pack_weight_frags: `natural_channels` leading input channels in S16 order (operands read
+ * from an S16 tensor), the rest in accumulator order (operands handed over in registers by the preceding layer):
+ * W2: natural 64; Wzr [256 x 192]: natural 128; Wq [128 x 192]: natural 0. */
+size_t tcs_weight_frags_bytes(int Cout, int Cin);
+int tcs_pack_weight_frags(const float* w_oi, int Cout, int Cin, int natural_channels, int scale_log2, void* packed, tcs_stream_t stream);
+int tcs_hidden_update_s16(void* h, int h_groups, const float* delta, const float* w1, const float* b1, const void* W2, const float* b2,
+                          float unscale2, const void* Wzr, const float* bzr, float unscale_zr, const void* Wq, const float* bq,
+                          float unscale_q, int B, int H, int W, tcs_stream_t stream);
+
 /* nn.Conv2d / ConvGRU step on S16 activations (core/update.py:16-17,26-36,57-68,77-87,103-111,198-214,291-305) */
 int tcs_conv2d_s16(const tcs_conv_s16_desc* desc, tcs_stream_t stream);
 

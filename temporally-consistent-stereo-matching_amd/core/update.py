@@ -72,16 +72,23 @@ def pool_of(module) -> s16.S16Pool:
     return p
 
 
+# A/B switches for benchmarking sessions (tools/, gpurun logs): comma-separated tokens in TCS_MI355_X.  Never set in production.
+_X = set(t for t in os.environ.get("TCS_MI355_X", "").split(",") if t)
+
+
 def conv16(pool, conv, srcs, act="none", addend=None, post_scale=1.0, out=None, want32=False, tag="o"):
     """A Conv2d on S16 sources -> S16 (a pool buffer owned by this conv, or `out`), or fp32 NCHW when want32."""
     a = srcs[0]
     stride = conv.stride[0]
     Ho, Wo = ((a.H - 1) // 2 + 1, (a.W - 1) // 2 + 1) if stride == 2 else (a.H, a.W)
+    tc = 0
+    if "t2" in _X and conv.kernel_size[0] == 3 and stride == 1 and a.H * a.W >= 10000:
+        tc = 101812                      # A/B: two-stage 8-row tiles on every 1/4-scale 3x3 layer
     if want32:
-        return s16.conv2d(packed16(conv), srcs, act=act, addend=addend, post_scale=post_scale, want32=True, stride=stride)[1]
+        return s16.conv2d(packed16(conv), srcs, act=act, addend=addend, post_scale=post_scale, want32=True, stride=stride, tile_cfg=tc)[1]
     if out is None:
         out = pool.get((id(conv), tag), a.B, conv.out_channels, Ho, Wo, a.device)
-    return s16.conv2d(packed16(conv), srcs, act=act, addend=addend, post_scale=post_scale, out16=out, stride=stride)[0]
+    return s16.conv2d(packed16(conv), srcs, act=act, addend=addend, post_scale=post_scale, out16=out, stride=stride, tile_cfg=tc)[0]
 
 
 def conv32to16(pool, conv, x, act="none", tag="o"):
@@ -225,8 +232,25 @@ class HiddenstateUpdater(_GateCell):
         super().__init__(hidden_dim, 64, 1)
         self.convs = nn.Sequential(_conv(1, 64, 1), nn.LeakyReLU(inplace=True), _conv(64, 64, 1))
 
+    def _frags(self):
+        """The cell's four weight matrices in the fused kernel's layouts, re-packed when a parameter changes."""
+        ps = [self.convs[0].weight, self.convs[0].bias, self.convs[2].weight, self.convs[2].bias, self.convzr.weight, self.convzr.bias,
+              self.convq.weight, self.convq.bias]
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        hit = getattr(self, "_tcs_frags", None)
+        if hit is None or hit[0] != key:
+            w1 = self.convs[0].weight.detach().float().reshape(64).contiguous()
+            b1 = self.convs[0].bias.detach().float().contiguous()
+            hit = (key, (w1, b1, s16.pack_frags(self.convs[2].weight, self.convs[2].bias, 64),
+                         s16.pack_frags(self.convzr.weight, self.convzr.bias, 128), s16.pack_frags(self.convq.weight, self.convq.bias, 0)))
+            self._tcs_frags = hit
+        return hit[1]
+
     def run(self, pool, h: s16.S16, delta: torch.Tensor) -> s16.S16:
-        x = conv32to16(pool, self.convs[0], delta, act="leaky")              # 1 -> 64 (single-channel kernel)
+        """One launch (tcs_hidden_update_s16): every layer is pixelwise, so a wave carries its 32 pixels through all of them."""
+        if h.C == 128 and self.convs[0].out_channels == 64 and "nohu" not in _X:
+            return s16.hidden_update(h, delta, *self._frags())
+        x = conv32to16(pool, self.convs[0], delta, act="leaky")              # generic widths: layer by layer
         x = conv16(pool, self.convs[2], [x])
         return self.step16(pool, h, [x])
 

@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void k_resize_bilinear_s16(const _Float16* __r
 // ---------------------------------------------------------------------------------------------------------------------
 #define INS_T 256
 #define INS_UPT 10                 // units per thread: a slice is up to 2560 pixels
+#define INS_MAXSL 16               // slices per plane the apply kernel merges in registers (planes up to 40,960 pixels)
 
 __device__ __forceinline__ void block_sum8(float* v, float* red /* [INS_T/64][8] */) {
 #pragma unroll
@@ -140,27 +141,31 @@ __global__ __launch_bounds__(INS_T) void k_in_apply_s16(const _Float16* __restri
     const int bg = blockIdx.y, sl = blockIdx.x, nsl = gridDim.x, b = bg / G, g = bg - b * G;
     const int HW = H * W, Wp = W + 2;
     const size_t plane = (size_t)(H + 2) * Wp * 8;
-    // merge the slices' (n_i, mean_i, M2_i): every thread does it for all 8 channels (<= 8 slices x 16 floats, L2 hits)
+    // merge the slices' (n_i, mean_i, M2_i): every thread does it for all 8 channels.  All partials (<= INS_MAXSL slices x 16
+    // floats, L2 hits) are fetched in ONE batch of independent loads: a loop of dependent-looking loads cost 8 us here.
     float mean[8], rstd[8];
     {
-        float tot[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int i = 0; i < nsl; ++i) {
-            const float ni = (float)(min(HW, (i + 1) * slice_px) - i * slice_px);
-            const float* pi = partial + ((size_t)bg * nsl + i) * 16;
+        float pm[INS_MAXSL][8], p2[INS_MAXSL][8], ns[INS_MAXSL];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) tot[j] += ni * pi[j];
+        for (int i = 0; i < INS_MAXSL; ++i) {
+            const int ic = min(i, nsl - 1);
+            const float4* pi = reinterpret_cast<const float4*>(partial + ((size_t)bg * nsl + ic) * 16);
+            const float4 m0 = pi[0], m1 = pi[1], q0 = pi[2], q1 = pi[3];
+            pm[i][0] = m0.x; pm[i][1] = m0.y; pm[i][2] = m0.z; pm[i][3] = m0.w; pm[i][4] = m1.x; pm[i][5] = m1.y; pm[i][6] = m1.z; pm[i][7] = m1.w;
+            p2[i][0] = q0.x; p2[i][1] = q0.y; p2[i][2] = q0.z; p2[i][3] = q0.w; p2[i][4] = q1.x; p2[i][5] = q1.y; p2[i][6] = q1.z; p2[i][7] = q1.w;
+            ns[i] = i < nsl ? (float)(min(HW, (i + 1) * slice_px) - i * slice_px) : 0.f;
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) mean[j] = tot[j] / (float)HW;
-        float m2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int i = 0; i < nsl; ++i) {
-            const float ni = (float)(min(HW, (i + 1) * slice_px) - i * slice_px);
-            const float* pi = partial + ((size_t)bg * nsl + i) * 16;
+        for (int j = 0; j < 8; ++j) {
+            float tot = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float d = pi[j] - mean[j]; m2[j] += pi[8 + j] + ni * d * d; }
+            for (int i = 0; i < INS_MAXSL; ++i) tot += ns[i] * pm[i][j];
+            mean[j] = tot / (float)HW;
+            float m2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < INS_MAXSL; ++i) { const float dd = pm[i][j] - mean[j]; m2 += ns[i] > 0.f ? p2[i][j] + ns[i] * dd * dd : 0.f; }
+            rstd[j] = 1.0f / sqrtf(m2 / (float)HW + eps);
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) rstd[j] = 1.0f / sqrtf(m2[j] / (float)HW + eps);
     }
     const _Float16* s = x + ((size_t)bg * 2) * plane;
     const _Float16* ad = addend ? addend + (((size_t)b * Ga + g) * 2) * plane : nullptr;
@@ -265,6 +270,7 @@ int tcs_instance_norm_s16(const void* x, int B, int groups, int H, int W, float 
     if ((long long)B * groups > 65535) return TCS_EUNSUPPORTED;
     if (out_groups != groups || (addend && addend_groups != groups)) return TCS_EUNSUPPORTED;   // same-shape tensors only
     const int HW = H * W, nsl = tcs_cdiv(HW, INS_T * INS_UPT), slice = tcs_cdiv(HW, nsl);
+    if (nsl > INS_MAXSL) return TCS_EUNSUPPORTED;
     hipStream_t s = tcs_stream(stream);
     hipLaunchKernelGGL(k_in_stats_s16, dim3(nsl, B * groups), dim3(INS_T), 0, s, reinterpret_cast<const _Float16*>(x), groups, H, W, slice,
                        reinterpret_cast<float*>(workspace));
@@ -286,6 +292,289 @@ int tcs_s16_set_channel(const float* x, int B, int H, int W, void* s16, int grou
     if (!x || !s16 || B <= 0 || B > 65535 || H <= 0 || W <= 0 || channel < 0 || channel >= groups_total * 8) return TCS_EINVAL;
     hipLaunchKernelGGL(k_s16_set_channel, dim3(tcs_cdiv((long long)H * W, 256), B), dim3(256), 0, tcs_stream(stream), x, H, W,
                        reinterpret_cast<_Float16*>(s16), groups_total, channel);
+    return tcs_launch_status();
+}
+
+}  // extern "C"
+
+// =====================================================================================================================
+// HiddenstateUpdater (core/update.py:57-68) as ONE launch.
+//
+//   x  = W2 . LeakyReLU(w1 * delta + b1) + b2                       1 -> 64 -> 64     (1x1)
+//   z, r = sigmoid(Wzr . [h, x] + bzr)                              192 -> 256        (1x1)
+//   q  = tanh(Wq . [r*h, x] + bq)                                   192 -> 128        (1x1)
+//   h' = z*h + (1-z)*q                                              in place on the S16 hidden state
+//
+// Every layer is pixelwise, so a wave keeps its 32 pixels from the first layer to the last: an accumulator tile
+// (32 channels x 32 pixels, pixel on the lane) becomes the B operand of the next layer's MFMAs after bias + activation +
+// fp16 split, with no LDS round trip and no lane movement (registers 8s..8s+7 of a tile are k-step s; the weights of
+// such K ranges are packed in the matching permuted channel order by tcs_pack_weight_frags).  h comes straight from
+// the S16 tensor in operand form.  Weights are read as ready-made A fragments (1 KiB per wave-load, L2-resident).
+// Four launches (single-channel conv, 64->64, zr, q: 62 us per iteration) become one.
+// =====================================================================================================================
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct HuArgs {
+    _Float16* h;                 // S16 [B][h_groups][2][H+2][W+2][8], 128 channels, updated in place
+    int h_groups;
+    const float* delta;          // [B,1,H,W]
+    const float* w1; const float* b1;            // convs[0]: [64] each
+    const uint4* W2; const float* b2;            // fragment-packed 64x64, natural K
+    const uint4* Wzr; const float* bzr;          // 256 x (128 natural | 64 permuted)
+    const uint4* Wq; const float* bq;            // 128 x (128 permuted | 64 permuted)
+    float us2, uszr, usq;                        // 2^-scale of the packed weights
+    int B, H, W;
+};
+
+__device__ __forceinline__ half8 hu_ldA(const uint4* w, int idx) {   // idx in 16-byte units, already includes the lane
+    const uint4 v = w[idx];
+    return *reinterpret_cast<const half8*>(&v);
+}
+
+#define HU_MMA3(ACC, AHI, ALO, BHI, BLO)                                          \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ALO, BHI, ACC, 0, 0, 0);        \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(AHI, BLO, ACC, 0, 0, 0);        \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(AHI, BHI, ACC, 0, 0, 0);
+
+// accumulator registers 8*sub .. 8*sub+7 of a tile (already bias-added / activated, fp32) -> B fragment (hi, lo) of a k-step
+__device__ __forceinline__ void hu_frag_from_acc(const float* v8, half8& hi, half8& lo) { split8(v8, hi, lo); }
+
+// One MFMA K loop over NK k-steps for NT (even) output tiles T0 .. T0+NT-1 of a packed matrix with NTT tiles per k-step.
+// The A fragments are double-buffered in registers by INLINE-ASM loads with counted waits: the 2*NT loads of k-step s+1 are in
+// flight during the 3*NT MFMAs of k-step s.  (A wave runs alone on its SIMD here, so nothing else hides the L2 latency of
+// the weight fragments, and hipcc sinks compiler-visible loads next to their first use: load -> vmcnt(0) -> MFMA, 277 times.)
+// Two tiles share one SGPR base (the immediate offset field is 13 bits).  BFRAG(s, bh, bl) yields the B operand of k-step s.
+#define HU_LDA(DST, BASE, IMM) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(DST) : "v"(voffA), "s"(BASE), "i"(IMM) : "memory")
+#define HU_WAITV(N) { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define HU_ISSUE(DH, DL, NT, WBASE, NTT, T0, S)                                                                   \
+    _Pragma("unroll") for (int t = 0; t < NT; t += 2) {                                                           \
+        const char* base_ = uniform_ptr_ops(reinterpret_cast<const char*>(WBASE) + (size_t)(((S) * (NTT) + (T0) + t) * 2) * 1024); \
+        HU_LDA(DH[t], base_, 0);                                                                                  \
+        HU_LDA(DL[t], base_, 1024);                                                                               \
+        HU_LDA(DH[t + 1], base_, 2048);                                                                           \
+        HU_LDA(DL[t + 1], base_, 3072);                                                                           \
+    }
+#define HU_GEMM(ACC, NT, NK, WBASE, NTT, T0, BFRAG)                                                               \
+    {                                                                                                             \
+        half8 a0h[NT], a0l[NT], a1h[NT], a1l[NT];                                                                 \
+        HU_ISSUE(a0h, a0l, NT, WBASE, NTT, T0, 0)                                                                 \
+        _Pragma("unroll") for (int s = 0; s < NK; s += 2) {                                                       \
+            if (s + 1 < NK) { HU_ISSUE(a1h, a1l, NT, WBASE, NTT, T0, s + 1) HU_WAITV(2 * NT) } else HU_WAITV(0)   \
+            {                                                                                                     \
+                half8 bh_, bl_;                                                                                   \
+                BFRAG(s, bh_, bl_)                                                                                \
+                _Pragma("unroll") for (int t = 0; t < NT; ++t) { HU_MMA3(ACC[t], a0h[t], a0l[t], bh_, bl_) }      \
+            }                                                                                                     \
+            if (s + 1 < NK) {                                                                                     \
+                if (s + 2 < NK) { HU_ISSUE(a0h, a0l, NT, WBASE, NTT, T0, s + 2) HU_WAITV(2 * NT) } else HU_WAITV(0) \
+                half8 bh_, bl_;                                                                                   \
+                BFRAG(s + 1, bh_, bl_)                                                                            \
+                _Pragma("unroll") for (int t = 0; t < NT; ++t) { HU_MMA3(ACC[t], a1h[t], a1l[t], bh_, bl_) }      \
+            }                                                                                                     \
+        }                                                                                                         \
+    }
+
+__device__ __forceinline__ const char* uniform_ptr_ops(const char* p) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+
+// sigmoid / tanh on the hardware exp2 and reciprocal (v_exp_f32, v_rcp_f32: <= 1 ulp each; |error| of the gate < 3e-7).  The
+// K loops of this kernel are 12 k-steps long, so the IEEE division + expf of the conv epilogues (~45 instructions per value,
+// 192 values per lane) would cost as much issue time as all of its MFMAs.
+__device__ __forceinline__ float hu_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)); }
+__device__ __forceinline__ float hu_tanh(float v) {
+    const float e = __builtin_amdgcn_exp2f(2.8853900817779268f * fminf(fmaxf(v, -15.f), 15.f));     // exp(2v)
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+#define HU_WAVES 2
+#define HU_NBIAS (64 + 64 + 64 + 256 + 128)           // w1, b1, b2, bzr, bq
+__global__ __launch_bounds__(64 * HU_WAVES) void k_hidden_update_s16(HuArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float hu_lds[];            // [HU_NBIAS] biases, then z gates: [wave][64 regs][64 lanes]
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int npx = (a.W + 31) / 32;
+    const int b = blockIdx.y;
+    const int y = (blockIdx.x / npx) * HU_WAVES + wave, x = (blockIdx.x % npx) * 32 + l31;
+    const bool active = y < a.H && x < a.W;
+    const int yc = min(y, a.H - 1), xc = min(x, a.W - 1);                       // clamped: inactive lanes compute on a valid pixel
+    const int Hp = a.H + 2, Wp = a.W + 2;
+    const size_t plane = (size_t)Hp * Wp * 8;
+    float* zl = hu_lds + HU_NBIAS + (size_t)wave * 64 * 64 + lane;
+    const unsigned voffA = (unsigned)lane * 16u;
+    // biases (and the single-channel first layer) through LDS: per-lane global loads of them inside the activation code
+    // serialised on ~90 separate memory round trips
+    for (int i = threadIdx.x; i < HU_NBIAS; i += 64 * HU_WAVES)
+        hu_lds[i] = i < 64 ? a.w1[i] : (i < 128 ? a.b1[i - 64] : (i < 192 ? a.b2[i - 128] : (i < 448 ? a.bzr[i - 192] : a.bq[i - 448])));
+    const float* s_w1 = hu_lds, *s_b1 = hu_lds + 64, *s_b2 = hu_lds + 128, *s_bzr = hu_lds + 192, *s_bq = hu_lds + 448;
+
+    // the 8 h fragments (B operands of the z|r layer: 128 channels in S16 order) are fetched once, up front
+    half8 hbh[8], hbl[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const _Float16* u = a.h + s16_unit(b, a.h_groups, 2 * s + hh, 0, Hp, Wp, yc, xc);
+        hbh[s] = *reinterpret_cast<const half8*>(u);
+        hbl[s] = *reinterpret_cast<const half8*>(u + plane);
+    }
+    // ---- layer 1 (VALU) straight into B-operand form: channel 16s + 8hh + j ------------------------------------------
+    const float d = a.delta[((size_t)b * a.H + yc) * a.W + xc];
+    __syncthreads();
+    HU_WAITV(0)              // the compiler-visible loads above have landed: from here on vmcnt is counted by hand
+    half8 x1h[4], x1l[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = 16 * s + 8 * hh + j;
+            const float t = fmaf(s_w1[c], d, s_b1[c]);
+            v[j] = t > 0.f ? t : 0.01f * t;
+        }
+        split8(v, x1h[s], x1l[s]);
+    }
+    // ---- layer 2: x = W2 . x1 + b2 -> fragments of 4 k-steps --------------------------------------------------------------
+    half8 xh[4], xl[4];
+    {
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+#define HU_B_X1(S, BH, BL) { BH = x1h[(S) < 4 ? (S) : 0]; BL = x1l[(S) < 4 ? (S) : 0]; }
+        HU_GEMM(acc, 2, 4, a.W2, 2, 0, HU_B_X1)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = acc[t][i] * a.us2 + s_b2[32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh];
+            hu_frag_from_acc(v, xh[2 * t], xl[2 * t]);
+            hu_frag_from_acc(v + 8, xh[2 * t + 1], xl[2 * t + 1]);
+        }
+    }
+#define HU_B_HX(S, BH, BL) { if ((S) < 8) { BH = hbh[(S) < 8 ? (S) : 0]; BL = hbl[(S) < 8 ? (S) : 0]; } else { BH = xh[(S) >= 8 ? (S) - 8 : 0]; BL = xl[(S) >= 8 ? (S) - 8 : 0]; } }
+    // ---- z = sigmoid(Wzr[0:128] . [h, x] + bz): tiles 0-3 of the packed z|r matrix (8 tiles per k-step) -> LDS ----------
+    {
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        {
+            HU_GEMM(acc, 4, 12, a.Wzr, 8, 0, HU_B_HX)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float pre = acc[t][i] * a.uszr + s_bzr[32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh];
+                    zl[(t * 16 + i) * 64] = hu_sigmoid(pre);
+                    acc[t][i] = 0.f;
+                }
+            }
+            // ---- r = sigmoid(Wzr[128:256] . [h, x] + br): tiles 4-7; r*h -> fragments of the q layer's first 8 k-steps ----
+            HU_GEMM(acc, 4, 12, a.Wzr, 8, 4, HU_B_HX)
+        }
+        half8 rhh[8], rhl[8];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const _Float16* hp = a.h + s16_unit(b, a.h_groups, 4 * t + q, 0, Hp, Wp, yc, xc) + 4 * hh;
+                const half4 hi = *reinterpret_cast<const half4*>(hp);
+                const half4 lo = *reinterpret_cast<const half4*>(hp + plane);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = 4 * q + j;
+                    const float pre = acc[t][i] * a.uszr + s_bzr[128 + 32 * t + 8 * q + 4 * hh + j];
+                    v[i] = ((float)hi[j] + (float)lo[j]) * hu_sigmoid(pre);
+                }
+            }
+            hu_frag_from_acc(v, rhh[2 * t], rhl[2 * t]);
+            hu_frag_from_acc(v + 8, rhh[2 * t + 1], rhl[2 * t + 1]);
+        }
+        HU_WAITV(0)          // (the h loads of the r*h products)
+        // ---- q = tanh(Wq . [r*h, x] + bq); h' = z*h + (1-z)*q ----------------------------------------------------------------
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+#define HU_B_RHX(S, BH, BL) { if ((S) < 8) { BH = rhh[(S) < 8 ? (S) : 0]; BL = rhl[(S) < 8 ? (S) : 0]; } else { BH = xh[(S) >= 8 ? (S) - 8 : 0]; BL = xl[(S) >= 8 ? (S) - 8 : 0]; } }
+        HU_GEMM(acc, 4, 12, a.Wq, 4, 0, HU_B_RHX)
+        if (!active) return;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                _Float16* hp = a.h + s16_unit(b, a.h_groups, 4 * t + q, 0, Hp, Wp, y, x) + 4 * hh;
+                const half4 hi = *reinterpret_cast<const half4*>(hp);
+                const half4 lo = *reinterpret_cast<const half4*>(hp + plane);
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = 4 * q + j;
+                    const float qv = hu_tanh(acc[t][i] * a.usq + s_bq[32 * t + 8 * q + 4 * hh + j]);
+                    const float z = zl[(t * 16 + i) * 64], hv = (float)hi[j] + (float)lo[j];
+                    v[j] = z * hv + (1.f - z) * qv;
+                }
+                s16_store4(hp, plane, v, 4);
+            }
+        }
+    }
+}
+
+// [Cout][Cin] fp32 (1x1 weights) * 2^scale -> A fragments of v_mfma_f32_32x32x16_f16, (hi, lo) split:
+// unit index ((kstep * ntiles + tile) * 2 + part) * 64 + lane, lane (m = l & 31, hh = l >> 5), element j = channel
+//   kstep*16 + 8*hh + j                    for k-steps < nat_ksteps (B operand in S16 / natural order), else
+//   kstep*16 + 8*(j>>2) + 4*hh + (j&3)     (B operand = accumulator registers of a preceding layer).
+__global__ __launch_bounds__(256) void k_pack_weight_frags(const float* __restrict__ w, int Cout, int Cin, int nk, int ntiles, int nat_ksteps,
+                                                            float scale, uint4* __restrict__ packed) {
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= nk * ntiles * 128) return;
+    const int lane = u & 63, part = (u >> 6) & 1, tile = (u >> 7) % ntiles, ks = (u >> 7) / ntiles;
+    const int m = lane & 31, hh = lane >> 5, co = tile * 32 + m;
+    half8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ci = ks * 16 + (ks < nat_ksteps ? 8 * hh + j : 8 * (j >> 2) + 4 * hh + (j & 3));
+        float xw = (co < Cout && ci < Cin) ? w[(size_t)co * Cin + ci] * scale : 0.f;
+        xw = __builtin_amdgcn_fmed3f(xw, -65504.f, 65504.f);
+        const _Float16 hi = (_Float16)xw, lo = (_Float16)(xw - (float)hi);
+        v[j] = part ? lo : hi;
+    }
+    packed[u] = *reinterpret_cast<uint4*>(&v);
+}
+
+extern "C" {
+
+size_t tcs_weight_frags_bytes(int Cout, int Cin) {
+    if (Cout <= 0 || Cin <= 0) return 0;
+    return (size_t)((Cin + 15) / 16) * ((Cout + 31) / 32) * 128 * 16;
+}
+
+int tcs_pack_weight_frags(const float* w_oi, int Cout, int Cin, int natural_channels, int scale_log2, void* packed, tcs_stream_t stream) {
+    if (!w_oi || !packed || Cout <= 0 || Cin <= 0 || natural_channels < 0 || natural_channels % 16 != 0 || natural_channels > Cin ||
+        scale_log2 < -60 || scale_log2 > 60) return TCS_EINVAL;
+    const int nk = (Cin + 15) / 16, ntiles = (Cout + 31) / 32, n = nk * ntiles * 128;
+    hipLaunchKernelGGL(k_pack_weight_frags, dim3((n + 255) / 256), dim3(256), 0, tcs_stream(stream), w_oi, Cout, Cin, nk, ntiles,
+                       natural_channels / 16, ldexpf(1.0f, scale_log2), reinterpret_cast<uint4*>(packed));
+    return tcs_launch_status();
+}
+
+int tcs_hidden_update_s16(void* h, int h_groups, const float* delta, const float* w1, const float* b1, const void* W2, const float* b2,
+                          float unscale2, const void* Wzr, const float* bzr, float unscale_zr, const void* Wq, const float* bq,
+                          float unscale_q, int B, int H, int W, tcs_stream_t stream) {
+    if (!h || !delta || !w1 || !b1 || !W2 || !b2 || !Wzr || !bzr || !Wq || !bq || h_groups < 16 || B <= 0 || B > 65535 || H <= 0 || W <= 0)
+        return TCS_EINVAL;
+    HuArgs a;
+    a.h = reinterpret_cast<_Float16*>(h); a.h_groups = h_groups; a.delta = delta; a.w1 = w1; a.b1 = b1;
+    a.W2 = reinterpret_cast<const uint4*>(W2); a.b2 = b2; a.Wzr = reinterpret_cast<const uint4*>(Wzr); a.bzr = bzr;
+    a.Wq = reinterpret_cast<const uint4*>(Wq); a.bq = bq; a.us2 = unscale2; a.uszr = unscale_zr; a.usq = unscale_q;
+    a.B = B; a.H = H; a.W = W;
+    const size_t lds = ((size_t)HU_NBIAS + (size_t)HU_WAVES * 64 * 64) * sizeof(float);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_hidden_update_s16, dim3(tcs_cdiv(W, 32) * tcs_cdiv(H, HU_WAVES), B), dim3(64 * HU_WAVES), lds, tcs_stream(stream), a);
     return tcs_launch_status();
 }
 

@@ -103,6 +103,9 @@ SIGNATURES = {
     "tcs_instance_norm_s16": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_f, c_int, c_fp, c_int, c_fp, c_int, c_fp, c_fp]),
     "tcs_propagate_disparity_s16": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_int, c_fp]),
     "tcs_s16_set_channel": (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_int, c_int, c_fp]),
+    "tcs_weight_frags_bytes": (c_sz, [c_int, c_int]),
+    "tcs_pack_weight_frags": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp]),
+    "tcs_hidden_update_s16": (c_int, [c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_f, c_fp, c_fp, c_f, c_int, c_int, c_int, c_fp]),
     "tcs_softmax_blend_s16": (c_int, [c_fp, c_fp, c_int, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp]),
 }
 

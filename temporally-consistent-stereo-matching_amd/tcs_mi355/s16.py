@@ -294,3 +294,38 @@ def softmax_blend(logits9, cand9, disp_q, coords1, flow_x, flow_x_s16: Optional[
                                             None if flow_x_s16 is None else flow_x_s16.ptr(), 0 if flow_x_s16 is None else flow_x_s16.G,
                                             int(flow_x_channel), nv.stream()), "tcs_softmax_blend_s16")
     return refined, delta
+
+
+# ---------------------------------------------------------------------------------------------
+# fused pixelwise chains
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class FragWeights:
+    """A 1x1 weight matrix as MFMA A fragments (tcs_pack_weight_frags)."""
+    data: torch.Tensor
+    bias: torch.Tensor
+    unscale: float
+
+
+def pack_frags(weight: torch.Tensor, bias: Optional[torch.Tensor], natural_channels: int) -> FragWeights:
+    cout, cin = int(weight.shape[0]), int(weight.shape[1])
+    w = weight.detach().float().reshape(cout, cin).contiguous()
+    wmax = float(w.abs().max())
+    import math
+    s_log2 = 0 if wmax == 0.0 else max(-40, min(40, int(12 - math.floor(math.log2(wmax)))))
+    L = nv.lib()
+    buf = torch.empty(L.tcs_weight_frags_bytes(cout, cin) // 4, dtype=torch.float32, device=w.device)
+    nv.check(L.tcs_pack_weight_frags(nv.ptr(w, "weight"), cout, cin, int(natural_channels), s_log2, nv.ptr(buf), nv.stream()),
+             "tcs_pack_weight_frags")
+    b = torch.zeros(cout, dtype=torch.float32, device=w.device) if bias is None else bias.detach().float().contiguous()
+    return FragWeights(buf, b, 2.0 ** (-s_log2))
+
+
+def hidden_update(h: S16, delta: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, W2: FragWeights, Wzr: FragWeights, Wq: FragWeights) -> S16:
+    """HiddenstateUpdater (update.py:57-68) in one launch, `h` (128 channels) updated in place."""
+    if h.C != 128 or tuple(delta.shape) != (h.B, 1, h.H, h.W):
+        raise ValueError("hidden_update: h must carry 128 channels and delta must be [B,1,H,W]")
+    nv.check(nv.lib().tcs_hidden_update_s16(h.ptr(), h.G, nv.ptr(delta, "delta"), nv.ptr(w1), nv.ptr(b1), nv.ptr(W2.data), nv.ptr(W2.bias),
+                                            W2.unscale, nv.ptr(Wzr.data), nv.ptr(Wzr.bias), Wzr.unscale, nv.ptr(Wq.data), nv.ptr(Wq.bias),
+                                            Wq.unscale, h.B, h.H, h.W, nv.stream()), "tcs_hidden_update_s16")
+    return h

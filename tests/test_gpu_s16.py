@@ -187,3 +187,27 @@ def test_glue_s16_vs_torch(dev):
     assert maxdiff(co, xs - r.cpu()) <= 1e-6 and maxdiff(fx, co.cpu() - xs) <= 1e-5
     assert maxdiff(s16.from_s16(buf, 128)[:, 127:], fx) <= 2.0 ** -21 * 64
     assert float(s16.from_s16(buf, 128)[:, :127].abs().max()) == 0
+
+
+def test_hidden_update_fused_vs_torch(dev):
+    """tcs_hidden_update_s16 (HiddenstateUpdater, update.py:57-68, one launch) against fp64 PyTorch, ragged grid, batch 2."""
+    from tcs_mi355 import s16
+    gen = torch.Generator().manual_seed(21)
+    B, H, W = 2, 11, 45
+    h = torch.tanh(torch.randn(B, 128, H, W, generator=gen))
+    delta = torch.randn(B, 1, H, W, generator=gen) * 2
+    w1, b1 = torch.randn(64, 1, 1, 1, generator=gen), torch.randn(64, generator=gen) * 0.1
+    w2, b2 = torch.randn(64, 64, 1, 1, generator=gen) * 0.15, torch.randn(64, generator=gen) * 0.1
+    wzr, bzr = torch.randn(256, 192, 1, 1, generator=gen) * 0.08, torch.randn(256, generator=gen) * 0.1
+    wq, bq = torch.randn(128, 192, 1, 1, generator=gen) * 0.08, torch.randn(128, generator=gen) * 0.1
+    x = F.conv2d(F.leaky_relu(F.conv2d(delta.double(), w1.double(), b1.double()), 0.01), w2.double(), b2.double())
+    zr = torch.sigmoid(F.conv2d(torch.cat([h.double(), x], 1), wzr.double(), bzr.double()))
+    z, r = zr[:, :128], zr[:, 128:]
+    q = torch.tanh(F.conv2d(torch.cat([r * h, x], 1), wq.double(), bq.double()))
+    ref = z * h + (1 - z) * q
+    h16 = s16.to_s16(D(h, dev))
+    out = s16.hidden_update(h16, D(delta, dev), D(w1.reshape(64), dev), D(b1, dev), s16.pack_frags(D(w2, dev), D(b2, dev), 64),
+                            s16.pack_frags(D(wzr, dev), D(bzr, dev), 128), s16.pack_frags(D(wq, dev), D(bq, dev), 0))
+    assert out is h16 and maxdiff(h16.float(), ref) <= 1e-5
+    d = h16.data.float().cpu()
+    assert float(d[:, :, :, 0].abs().max()) == 0 and float(d[:, :, :, :, -1].abs().max()) == 0        # border untouched

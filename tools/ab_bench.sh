@@ -1,0 +1,12 @@
+#!/bin/bash
+# A/B of end-to-end frame time inside ONE gpurun call (boxes differ by several percent): interleaved rounds of
+# `bench.py --steps 10` per variant, variants = values of TCS_MI355_X (use "-" for the default build).
+# usage: tools/ab_bench.sh <rounds> <variant> [<variant> ...]
+rounds=$1; shift
+for r in $(seq 1 $rounds); do
+  for v in "$@"; do
+    x=$v; [ "$v" = "-" ] && x=""
+    ms=$(TCS_MI355_X=$x python bench.py --steps 10 --warmup 3 --no-cpu-baseline --batched-leg 0 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.readline())['ms_per_step'])")
+    echo "round $r variant [$v] ms_per_step $ms"
+  done
+done
