@@ -64,13 +64,12 @@ __global__ __launch_bounds__(256) void k_resize_bilinear_s16(const _Float16* __r
 //   k_in_stats_s16: grid (slices, B*G).  A block reduces its slice of the plane for the 8 channels of its group with the
 //       plane slice held in registers: sum -> slice mean -> sum of squares AROUND that mean (the reference's two-pass
 //       variance, not E[x^2] - mean^2), and writes (mean_i, M2_i) per channel.
-//   k_in_apply_s16: every block first merges the partials of its (b, group) with Chan's formula
-//       (M2 = sum M2_i + n_i (mean_i - mean)^2), then normalises its own slice.
+//   k_in_apply_s16: one thread per unit; every thread merges the partials of its (b, group) with Chan's pairwise formula
+//       (M2 = M2_a + M2_b + d^2 n_a n_b / n), then normalises its unit.
 // A per-(b, channel) block like the fp32 kernel would leave a 64-channel tensor with 8 workgroups on 256 CUs.
 // ---------------------------------------------------------------------------------------------------------------------
 #define INS_T 256
 #define INS_UPT 10                 // units per thread: a slice is up to 2560 pixels
-#define INS_MAXSL 16               // slices per plane the apply kernel merges in registers (planes up to 40,960 pixels)
 
 __device__ __forceinline__ void block_sum8(float* v, float* red /* [INS_T/64][8] */) {
 #pragma unroll
@@ -135,52 +134,48 @@ __device__ __forceinline__ float s16_act(float v, int act) {
     }
 }
 
-__global__ __launch_bounds__(INS_T) void k_in_apply_s16(const _Float16* __restrict__ x, int G, int H, int W, int slice_px,
+__global__ __launch_bounds__(INS_T) void k_in_apply_s16(const _Float16* __restrict__ x, int G, int H, int W, int slice_px, int nsl,
                                                          const float* __restrict__ partial, float eps, int act,
                                                          const _Float16* __restrict__ addend, int Ga, _Float16* __restrict__ out, int Go) {
-    const int bg = blockIdx.y, sl = blockIdx.x, nsl = gridDim.x, b = bg / G, g = bg - b * G;
+    // one thread per unit (a 64-channel 1/4-scale tensor is 600 workgroups; a loop of 10 units per thread over 64 workgroups
+    // was 10 dependent memory round trips long: 25 us)
+    const int bg = blockIdx.y, b = bg / G, g = bg - b * G;
     const int HW = H * W, Wp = W + 2;
     const size_t plane = (size_t)(H + 2) * Wp * 8;
-    // merge the slices' (n_i, mean_i, M2_i): every thread does it for all 8 channels.  All partials (<= INS_MAXSL slices x 16
-    // floats, L2 hits) are fetched in ONE batch of independent loads: a loop of dependent-looking loads cost 8 us here.
-    float mean[8], rstd[8];
-    {
-        float pm[INS_MAXSL][8], p2[INS_MAXSL][8], ns[INS_MAXSL];
+    const int p = blockIdx.x * INS_T + threadIdx.x;
+    const bool ok = p < HW;
+    const int pc = ok ? p : HW - 1;
+    const int y = pc / W, xx = pc - y * W;
+    const size_t u = ((size_t)(y + 1) * Wp + xx + 1) * 8;
+    float v[8], t[8];
+    s16_load8(x + ((size_t)bg * 2) * plane + u, plane, v);
+    if (addend) s16_load8(addend + (((size_t)b * Ga + g) * 2) * plane + u, plane, t);
+    // merge the slices' (n_i, mean_i, M2_i) pairwise (Chan et al.): the loads do not depend on the running sums, so they
+    // are all in flight together; every lane reads the same addresses (one L2 transaction per wave-load)
+    float n = 0.f, mean[8], m2[8];
 #pragma unroll
-        for (int i = 0; i < INS_MAXSL; ++i) {
-            const int ic = min(i, nsl - 1);
-            const float4* pi = reinterpret_cast<const float4*>(partial + ((size_t)bg * nsl + ic) * 16);
-            const float4 m0 = pi[0], m1 = pi[1], q0 = pi[2], q1 = pi[3];
-            pm[i][0] = m0.x; pm[i][1] = m0.y; pm[i][2] = m0.z; pm[i][3] = m0.w; pm[i][4] = m1.x; pm[i][5] = m1.y; pm[i][6] = m1.z; pm[i][7] = m1.w;
-            p2[i][0] = q0.x; p2[i][1] = q0.y; p2[i][2] = q0.z; p2[i][3] = q0.w; p2[i][4] = q1.x; p2[i][5] = q1.y; p2[i][6] = q1.z; p2[i][7] = q1.w;
-            ns[i] = i < nsl ? (float)(min(HW, (i + 1) * slice_px) - i * slice_px) : 0.f;
-        }
+    for (int j = 0; j < 8; ++j) { mean[j] = 0.f; m2[j] = 0.f; }
+#pragma unroll 4
+    for (int i = 0; i < nsl; ++i) {
+        const float4* pi = reinterpret_cast<const float4*>(partial + ((size_t)bg * nsl + i) * 16);
+        const float4 a0 = pi[0], a1 = pi[1], q0 = pi[2], q1 = pi[3];
+        const float pm[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, p2[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        const float ni = (float)(min(HW, (i + 1) * slice_px) - i * slice_px), tot = n + ni, f = ni / tot;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float tot = 0.f;
-#pragma unroll
-            for (int i = 0; i < INS_MAXSL; ++i) tot += ns[i] * pm[i][j];
-            mean[j] = tot / (float)HW;
-            float m2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < INS_MAXSL; ++i) { const float dd = pm[i][j] - mean[j]; m2 += ns[i] > 0.f ? p2[i][j] + ns[i] * dd * dd : 0.f; }
-            rstd[j] = 1.0f / sqrtf(m2 / (float)HW + eps);
+            const float d = pm[j] - mean[j];
+            mean[j] += d * f;
+            m2[j] += p2[j] + d * d * n * f;
         }
+        n = tot;
     }
-    const _Float16* s = x + ((size_t)bg * 2) * plane;
-    const _Float16* ad = addend ? addend + (((size_t)b * Ga + g) * 2) * plane : nullptr;
-    _Float16* o = out + (((size_t)b * Go + g) * 2) * plane;
-    const int p_lo = sl * slice_px, p_hi = min(HW, p_lo + slice_px);
-    for (int p = p_lo + threadIdx.x; p < p_hi; p += INS_T) {
-        const int y = p / W, xx = p - y * W;
-        const size_t u = ((size_t)(y + 1) * Wp + xx + 1) * 8;
-        float v[8], t[8];
-        s16_load8(s + u, plane, v);
-        if (ad) s16_load8(ad + u, plane, t);
+    if (!ok) return;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = s16_act((v[j] - mean[j]) * rstd[j], act) + (ad ? t[j] : 0.f);
-        s16_store8(o + u, plane, v);
+    for (int j = 0; j < 8; ++j) {
+        const float rstd = 1.0f / sqrtf(m2[j] / (float)HW + eps);
+        v[j] = s16_act((v[j] - mean[j]) * rstd, act) + (addend ? t[j] : 0.f);
     }
+    s16_store8(out + (((size_t)b * Go + g) * 2) * plane + u, plane, v);
 }
 
 // update.py:259-289 with the stem's input laid out for tcs_conv2d_s16: out16 = S16 [B][4 groups][...] holding the 27
@@ -270,12 +265,12 @@ int tcs_instance_norm_s16(const void* x, int B, int groups, int H, int W, float 
     if ((long long)B * groups > 65535) return TCS_EUNSUPPORTED;
     if (out_groups != groups || (addend && addend_groups != groups)) return TCS_EUNSUPPORTED;   // same-shape tensors only
     const int HW = H * W, nsl = tcs_cdiv(HW, INS_T * INS_UPT), slice = tcs_cdiv(HW, nsl);
-    if (nsl > INS_MAXSL) return TCS_EUNSUPPORTED;
+
     hipStream_t s = tcs_stream(stream);
     hipLaunchKernelGGL(k_in_stats_s16, dim3(nsl, B * groups), dim3(INS_T), 0, s, reinterpret_cast<const _Float16*>(x), groups, H, W, slice,
                        reinterpret_cast<float*>(workspace));
-    hipLaunchKernelGGL(k_in_apply_s16, dim3(nsl, B * groups), dim3(INS_T), 0, s, reinterpret_cast<const _Float16*>(x), groups, H, W, slice,
-                       reinterpret_cast<const float*>(workspace), eps, act, reinterpret_cast<const _Float16*>(addend), addend_groups,
+    hipLaunchKernelGGL(k_in_apply_s16, dim3(tcs_cdiv(HW, INS_T), B * groups), dim3(INS_T), 0, s, reinterpret_cast<const _Float16*>(x), groups, H, W,
+                       slice, nsl, reinterpret_cast<const float*>(workspace), eps, act, reinterpret_cast<const _Float16*>(addend), addend_groups,
                        reinterpret_cast<_Float16*>(out), out_groups);
     return tcs_launch_status();
 }
