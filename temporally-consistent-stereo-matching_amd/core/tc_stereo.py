@@ -191,8 +191,10 @@ class TCStereo(nn.Module):
         motion = pool.get(("frame", "motion"), coords1.shape[0], 128, coords1.shape[2], coords1.shape[3], coords1.device)
         s16.set_channel(flows_x, motion, 127)
         ub = self.update_block
-        from tcs_mi355.streams import fork_join
+        from tcs_mi355.streams import fork_join, join, spawn
         hu_delta = None              # the hidden-state update of iteration i-1 runs at the head of iteration i's coarse branch
+        early32 = None               # gru32 of iteration i, launched during iteration i-1 (it needs only net16 / net32)
+        plain = not a.slow_fast_gru and n3
         for itr in range(iters):
             # Two independent chains open an iteration: [hidden-state update of the previous iteration -> gru32 -> gru16 ->
             # interp] needs only the hidden states; [corr lookup -> motion encoder] needs only coords1 / the flow written by the
@@ -208,9 +210,14 @@ class TCStereo(nn.Module):
                     ub.run_coarse(pool, nets, inp_list, iter16=False, iter32=True, want_up16=False)
                 if a.n_gru_layers >= 2 and a.slow_fast_gru:
                     ub.run_coarse(pool, nets, inp_list, iter16=True, iter32=n3, want_up16=False)
-                return ub.run_coarse(pool, nets, inp_list, iter16=a.n_gru_layers >= 2, iter32=n3)
+                return ub.run_coarse(pool, nets, inp_list, iter16=a.n_gru_layers >= 2, iter32=n3, up32=up32_now)
 
+            up32_now = join(early32)                     # (None on the first iteration: gru32 then runs inside the coarse branch)
+            early32 = None
             (corr, m), up16 = fork_join([enc_branch, coarse_branch], site="iter")
+            if plain and trace is None and itr + 1 < iters:
+                # net16 is final for this iteration: gru32 of the NEXT iteration runs beside gru08 / flow head / refinement
+                early32 = spawn(lambda: ub.run_gru32(pool, nets, inp_list), site="gru32")
             delta_flow = ub.run_fine(pool, nets, inp_list, m, up16)
             # disp_q = x - (coords1 + delta), 5 * disp2disp_gradient_xy (update.py:199) and the gradient candidates in one
             # launch; coords1 is replaced by the blend kernel's output below

@@ -361,18 +361,26 @@ class BasicMultiUpdateBlock(nn.Module):
             motion_out.copy_(motion.float())
         return (out, res) if update else out
 
-    def run_coarse(self, pool, net, inp, iter16=True, iter32=True, want_up16=True):
+    def run_gru32(self, pool, net, inp):
+        """gru32 on pool2x(net16) (update.py:147-148), in place, and interp(net32 -> 1/8 grid) for gru16.  Needs only net16 /
+        net32, so the frame loop launches it for iteration i+1 as soon as gru16 of iteration i is done (tc_stereo.py)."""
+        p = s16.avgpool3s2(net[1], out=pool.get((id(self), "pool16"), net[2].B, net[1].C, net[2].H, net[2].W, net[2].device))
+        self.gru32.step16(pool, net[2], [p], *inp[2])
+        return s16.resize_bilinear(net[2], net[1].H, net[1].W, out=pool.get((id(self), "up32"), net[1].B, net[2].C, net[1].H, net[1].W, net[1].device))
+
+    def run_coarse(self, pool, net, inp, iter16=True, iter32=True, want_up16=True, up32=None):
         """gru32 -> gru16 (update.py:147-153) on S16 states, in place; returns interp(net16 -> 1/4 grid) for gru08 (or None).
-        Independent of the motion encoder, which only feeds gru08."""
+        Independent of the motion encoder, which only feeds gru08.  `up32`: gru32 of this iteration already ran (run_gru32)."""
         n = self.args.n_gru_layers
-        if iter32:
-            p = s16.avgpool3s2(net[1], out=pool.get((id(self), "pool16"), net[2].B, net[1].C, net[2].H, net[2].W, net[2].device))
-            self.gru32.step16(pool, net[2], [p], *inp[2])
+        if iter32 and up32 is None:
+            up32 = self.run_gru32(pool, net, inp)
         if iter16:
             xs = [s16.avgpool3s2(net[0], out=pool.get((id(self), "pool08"), net[1].B, net[0].C, net[1].H, net[1].W, net[1].device))]
             if n > 2:
-                xs.append(s16.resize_bilinear(net[2], net[1].H, net[1].W,
-                                              out=pool.get((id(self), "up32"), net[1].B, net[2].C, net[1].H, net[1].W, net[1].device)))
+                if up32 is None:
+                    up32 = s16.resize_bilinear(net[2], net[1].H, net[1].W,
+                                               out=pool.get((id(self), "up32"), net[1].B, net[2].C, net[1].H, net[1].W, net[1].device))
+                xs.append(up32)
             self.gru16.step16(pool, net[1], xs, *inp[1])
         if want_up16 and n > 1:
             return s16.resize_bilinear(net[1], net[0].H, net[0].W,

@@ -33,6 +33,40 @@ def _side_streams(device, depth: int, n: int) -> List[torch.cuda.Stream]:
     return pool[:n]
 
 
+class Spawned:
+    """Handle of `spawn`: the result of the function and the side stream it was enqueued on (None = ran inline)."""
+
+    def __init__(self, result, stream):
+        self.result, self.stream = result, stream
+
+
+def spawn(fn: Callable[[], object], site: str = "") -> Spawned:
+    """Enqueue `fn` on a side stream behind everything already on the current stream and return at once; `join` makes the
+    current stream wait for it.  Used for work whose result is needed much later (the next iteration's gru32)."""
+    global _IN_SIDE, _DEPTH
+    if not ENABLED or _IN_SIDE > 0 or not torch.cuda.is_available() or ("all" not in SITES and site not in SITES):
+        return Spawned(fn(), None)
+    cur = torch.cuda.current_stream()
+    pool = _POOL.setdefault((cur.device, "spawn"), [])
+    if not pool:
+        pool.append(torch.cuda.Stream(device=cur.device))
+    st = pool[0]
+    st.wait_stream(cur)
+    _IN_SIDE += 1
+    try:
+        with torch.cuda.stream(st):
+            res = fn()
+    finally:
+        _IN_SIDE -= 1
+    return Spawned(res, st)
+
+
+def join(h: Spawned):
+    if h is not None and h.stream is not None:
+        torch.cuda.current_stream().wait_stream(h.stream)
+    return None if h is None else h.result
+
+
 def fork_join(fns: Sequence[Callable[[], object]], site: str = "") -> list:
     """Run fns[0] on the current stream and fns[1:] on side streams; returns their results after joining.
     Every side chain starts after everything already enqueued on the current stream and the current stream waits for
