@@ -119,30 +119,37 @@ def lookup_burst_us(dev, B, n=200, reps=5):
     coords = (xs - disp).contiguous().to(dev)
     out = ops.corr_lookup(pyr, coords, 4)
     torch.cuda.synchronize()
-    # every launch of the burst also stamps the device clock (first instruction of the first workgroup -> last acknowledged
-    # store of the last one): the kernel's own span with the pyramid hot in L2 / Infinity Cache
-    saved, probe = ops.LOOKUP_PROBE, ops.LookupProbe(dev, slots=n)
-    ops.LOOKUP_PROBE = probe
-    try:
-        g, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
-        with torch.cuda.stream(side):
-            with torch.cuda.graph(g, stream=side):
-                for _ in range(n):
-                    ops.corr_lookup(pyr, coords, 4, out=out)
-    finally:
-        ops.LOOKUP_PROBE = saved
-    g.replay()
-    torch.cuda.synchronize()
-    probe.reset()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
+
+    def burst(stamped):
+        # `stamped`: every launch also records the device clock (first instruction of the first workgroup -> last acknowledged
+        # store of the last one) into its own slot: the kernel's own span with the pyramid hot in L2 / Infinity Cache.  The
+        # event-timed burst runs WITHOUT stamps (they add a wait for the store acknowledgement and an atomic per wave).
+        saved, probe = ops.LOOKUP_PROBE, (ops.LookupProbe(dev, slots=n) if stamped else None)
+        ops.LOOKUP_PROBE = probe
+        try:
+            g, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, stream=side):
+                    for _ in range(n):
+                        ops.corr_lookup(pyr, coords, 4, out=out)
+        finally:
+            ops.LOOKUP_PROBE = saved
         g.replay()
-    e1.record()
-    torch.cuda.synchronize()
-    hot = probe.durations_us()
-    return e0.elapsed_time(e1) * 1e3 / (n * reps), (float(np.median(hot)) if hot else None)
+        torch.cuda.synchronize()
+        if probe is not None:
+            probe.reset()
+            torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / (n * reps), (probe.durations_us() if probe is not None else None)
+
+    events_us, _ = burst(False)
+    _, hot = burst(True)
+    return events_us, (float(np.median(hot)) if hot else None)
 
 
 def lookup_roofline(probe, snapshots, burst, pixels):

@@ -284,6 +284,11 @@ int tcs_conv2d(const tcs_conv_desc* desc, tcs_stream_t stream);
  * entry point above; tcs_s16_from_f32 / tcs_s16_to_f32 convert at the loop's boundary.
  * ------------------------------------------------------------------------------------------------------------------- */
 size_t tcs_s16_bytes(int B, int C, int H, int W);
+/* Domain guard of the split (|x| <= 65504): every producer of S16 data marks a device-side flag word when it had to clamp a
+ * finite value (bit 0) or met a NaN / Inf (bit 1) — the replacement of the reference's per-iteration NaN asserts
+ * (core/update.py:27-35,58-67,78-86,155-158).  Reads and clears the word; SYNCHRONISES the device (call it once per frame or
+ * sequence, outside any graph capture). */
+int tcs_s16_flags(unsigned int* flags_out);
 /* x [B,C,H,W] fp32 -> groups [group_offset, group_offset + 2*ceil(C/16)) of an S16 tensor with groups_total groups */
 int tcs_s16_from_f32(const float* x, int B, int C, int H, int W, void* s16, int groups_total, int group_offset, tcs_stream_t stream);
 /* channels [8*group_offset, 8*group_offset + C) of an S16 tensor -> out [B,C,H,W] fp32 (hi + lo) */

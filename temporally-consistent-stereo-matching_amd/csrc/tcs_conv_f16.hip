@@ -868,3 +868,12 @@ int tcs_pack_conv_weight_f16x3(const float* w_oihw, int Cout, int Cin, int ksize
 }
 
 }  // extern "C"
+
+// this translation unit's S16 domain flag (tcs_s16.h): read-and-clear for tcs_s16_flags()
+int tcs_s16_flag_take_conv_f16(unsigned int* out) {
+    unsigned int v = 0, zero = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(TCS_S16_FLAG_VAR), sizeof(v)) != hipSuccess) return TCS_ELAUNCH;
+    if (v && hipMemcpyToSymbol(HIP_SYMBOL(TCS_S16_FLAG_VAR), &zero, sizeof(zero)) != hipSuccess) return TCS_ELAUNCH;
+    *out |= v;
+    return TCS_OK;
+}

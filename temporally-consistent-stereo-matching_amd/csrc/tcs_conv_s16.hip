@@ -657,3 +657,12 @@ int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
 }
 
 }  // extern "C"
+
+// this translation unit's S16 domain flag (tcs_s16.h): read-and-clear for tcs_s16_flags()
+int tcs_s16_flag_take_conv_s16(unsigned int* out) {
+    unsigned int v = 0, zero = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(TCS_S16_FLAG_VAR), sizeof(v)) != hipSuccess) return TCS_ELAUNCH;
+    if (v && hipMemcpyToSymbol(HIP_SYMBOL(TCS_S16_FLAG_VAR), &zero, sizeof(zero)) != hipSuccess) return TCS_ELAUNCH;
+    *out |= v;
+    return TCS_OK;
+}

@@ -8,8 +8,26 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
+// Domain guard of the split: |x| <= 65504.  A value outside it is clamped (a NaN becomes 65504) and leaves a mark in a
+// device-side flag word that the host can read once per frame (tcs_s16_flags): bit 0 = a finite value was saturated,
+// bit 1 = a non-finite value was seen.  One flag word per translation unit that includes this header (no relocatable
+// device code): tcs_s16_flags ORs them.  The test costs two compares per pair; the atomic runs only on a violation.
+#ifndef TCS_S16_FLAG_VAR
+#define TCS_S16_FLAG_VAR tcs_s16_flag_word
+#endif
+static __device__ unsigned int TCS_S16_FLAG_VAR;
+
+__device__ __forceinline__ void s16_guard(float x0, float x1) {
+    const bool bad = !(fabsf(x0) <= 65504.f) || !(fabsf(x1) <= 65504.f);
+    if (__builtin_expect(bad, 0)) {
+        const bool nonfinite = !(fabsf(x0) <= 3.402823466e38f) || !(fabsf(x1) <= 3.402823466e38f);
+        atomicOr(&TCS_S16_FLAG_VAR, nonfinite ? 2u : 1u);
+    }
+}
+
 // x = hi + lo (+ <= 2^-22 |x|); |x| saturates at 65504 (fp16 range); two values per v_cvt_pk_f16_f32
 __device__ __forceinline__ void s16_split2(float x0, float x1, half2_t& hi, half2_t& lo) {
+    s16_guard(x0, x1);
     float2_t x;
     x[0] = __builtin_amdgcn_fmed3f(x0, -65504.f, 65504.f);
     x[1] = __builtin_amdgcn_fmed3f(x1, -65504.f, 65504.f);

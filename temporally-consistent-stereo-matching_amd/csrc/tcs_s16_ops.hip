@@ -375,13 +375,24 @@ __device__ __forceinline__ const char* uniform_ptr_ops(const char* p) {
     return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
 }
 
-// sigmoid / tanh on the hardware exp2 and reciprocal (v_exp_f32, v_rcp_f32: <= 1 ulp each; |error| of the gate < 3e-7).  The
-// K loops of this kernel are 12 k-steps long, so the IEEE division + expf of the conv epilogues (~45 instructions per value,
-// 192 values per lane) would cost as much issue time as all of its MFMAs.
-__device__ __forceinline__ float hu_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)); }
+// sigmoid / tanh on the hardware exp2 and reciprocal with one correction step each: exp(x) = 2^(x*log2e) with the rounding
+// error of the product folded back in (e * (1 + lo*ln2)), 1/d by v_rcp_f32 + one Newton step: <= 1-2 ulp, like expf and an IEEE
+// division, at 9 instead of ~45 instructions per value.  The K loops of this kernel are 12 k-steps long, so the library
+// versions (192 values per lane) would cost as much issue time as all of its MFMAs.
+__device__ __forceinline__ float hu_exp(float x) {
+    const float hi = x * 1.4426950408889634f;
+    const float lo = fmaf(x, 1.4426950408889634f, -hi) + x * 1.9259629911266175e-8f;      // product rounding + log2(e) tail
+    const float e = __builtin_amdgcn_exp2f(hi);
+    return fmaf(e, lo * 0.6931471805599453f, e);
+}
+__device__ __forceinline__ float hu_rcp(float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
+__device__ __forceinline__ float hu_sigmoid(float v) { return hu_rcp(1.0f + hu_exp(-v)); }
 __device__ __forceinline__ float hu_tanh(float v) {
-    const float e = __builtin_amdgcn_exp2f(2.8853900817779268f * fminf(fmaxf(v, -15.f), 15.f));     // exp(2v)
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+    const float e = hu_exp(2.0f * fminf(fmaxf(v, -15.f), 15.f));
+    return 1.0f - 2.0f * hu_rcp(e + 1.0f);
 }
 
 #define HU_WAVES 2
@@ -541,7 +552,26 @@ __global__ __launch_bounds__(256) void k_pack_weight_frags(const float* __restri
     packed[u] = *reinterpret_cast<uint4*>(&v);
 }
 
+int tcs_s16_flag_take_conv_s16(unsigned int*);
+int tcs_s16_flag_take_s16_ops(unsigned int*);
+int tcs_s16_flag_take_conv(unsigned int*);
+int tcs_s16_flag_take_conv_f16(unsigned int*);
+int tcs_s16_flag_take_stencil(unsigned int*);
+
 extern "C" {
+
+int tcs_s16_flags(unsigned int* flags_out) {
+    if (!flags_out) return TCS_EINVAL;
+    if (hipDeviceSynchronize() != hipSuccess) return TCS_ELAUNCH;
+    unsigned int v = 0;
+    int rc = tcs_s16_flag_take_conv_s16(&v);
+    if (rc == TCS_OK) rc = tcs_s16_flag_take_s16_ops(&v);
+    if (rc == TCS_OK) rc = tcs_s16_flag_take_conv(&v);
+    if (rc == TCS_OK) rc = tcs_s16_flag_take_conv_f16(&v);
+    if (rc == TCS_OK) rc = tcs_s16_flag_take_stencil(&v);
+    *flags_out = v;
+    return rc;
+}
 
 size_t tcs_weight_frags_bytes(int Cout, int Cin) {
     if (Cout <= 0 || Cin <= 0) return 0;
@@ -574,3 +604,12 @@ int tcs_hidden_update_s16(void* h, int h_groups, const float* delta, const float
 }
 
 }  // extern "C"
+
+// this translation unit's S16 domain flag (tcs_s16.h): read-and-clear for tcs_s16_flags()
+int tcs_s16_flag_take_s16_ops(unsigned int* out) {
+    unsigned int v = 0, zero = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(TCS_S16_FLAG_VAR), sizeof(v)) != hipSuccess) return TCS_ELAUNCH;
+    if (v && hipMemcpyToSymbol(HIP_SYMBOL(TCS_S16_FLAG_VAR), &zero, sizeof(zero)) != hipSuccess) return TCS_ELAUNCH;
+    *out |= v;
+    return TCS_OK;
+}

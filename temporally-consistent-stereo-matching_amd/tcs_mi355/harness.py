@@ -65,6 +65,7 @@ class FrameStats:
 @dataclass
 class SequenceStats:
     frames: List[FrameStats] = field(default_factory=list)
+    domain_flags: int = 0        # tcs_s16_flags after the sequence: bit 0 = an activation was clamped at +-65504, bit 1 = NaN / Inf seen
 
     def vector(self) -> np.ndarray:
         """[sum_epe, sum_d1w, sum_d3w, sum_rate, n_frames]: what one rank contributes to the gather."""
@@ -123,6 +124,14 @@ def run_sequence(forward: Callable, seq, iters: int, device, temporal: bool = Tr
         fs = frame_metrics(disp_pr, gt)
         if fs is not None:
             stats.frames.append(fs)
+    if torch.device(device).type == "cuda":
+        # the device-side replacement of the reference's per-iteration NaN asserts: one read per sequence
+        from . import s16
+        stats.domain_flags = s16.take_flags()
+        if stats.domain_flags:
+            import warnings
+            warnings.warn(f"activations left the fp16-split domain during this sequence (flags {stats.domain_flags:#x}: "
+                          f"bit 0 = clamped at 65504, bit 1 = NaN/Inf)")
     return stats
 
 

@@ -329,3 +329,11 @@ def hidden_update(h: S16, delta: torch.Tensor, w1: torch.Tensor, b1: torch.Tenso
                                             W2.unscale, nv.ptr(Wzr.data), nv.ptr(Wzr.bias), Wzr.unscale, nv.ptr(Wq.data), nv.ptr(Wq.bias),
                                             Wq.unscale, h.B, h.H, h.W, nv.stream()), "tcs_hidden_update_s16")
     return h
+
+
+def take_flags() -> int:
+    """Read-and-clear the device-side domain flags of the S16 producers (synchronises): bit 0 = a finite activation beyond the
+    fp16 range was clamped to +-65504, bit 1 = a NaN / Inf was met.  The harness calls it once per sequence."""
+    v = C.c_uint(0)
+    nv.check(nv.lib().tcs_s16_flags(C.byref(v)), "tcs_s16_flags")
+    return int(v.value)

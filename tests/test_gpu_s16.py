@@ -211,3 +211,26 @@ def test_hidden_update_fused_vs_torch(dev):
     assert out is h16 and maxdiff(h16.float(), ref) <= 1e-5
     d = h16.data.float().cpu()
     assert float(d[:, :, :, 0].abs().max()) == 0 and float(d[:, :, :, :, -1].abs().max()) == 0        # border untouched
+
+
+def test_domain_guard_flags(dev):
+    """The split's domain (|x| <= 65504, finite) is guarded by a device-side flag word instead of the reference's host-synchronising
+    NaN asserts (update.py:27-35,...): saturation and non-finite values are reported, ordinary data is silent."""
+    from tcs_mi355 import ops, s16
+    s16.take_flags()                                                    # clear
+    x = torch.randn(1, 16, 8, 32)
+    s16.to_s16(D(x, dev))
+    assert s16.take_flags() == 0
+    big = x.clone()
+    big[0, 3, 2, 5] = 1.0e5
+    t = s16.to_s16(D(big, dev))
+    assert s16.take_flags() == 1 and float(t.float()[0, 3, 2, 5]) == 65504.0
+    nan = x.clone()
+    nan[0, 1, 0, 0] = float("nan")
+    s16.to_s16(D(nan, dev))
+    assert s16.take_flags() & 2
+    assert s16.take_flags() == 0                                        # read-and-clear
+    # a convolution whose output overflows the domain marks the flag from its epilogue
+    w = torch.full((32, 16, 3, 3), 500.0)
+    s16.conv2d(ops.pack_conv(D(w, dev), None, "f16x3"), [s16.to_s16(D(torch.full((1, 16, 8, 32), 10.0), dev))])
+    assert s16.take_flags() & 1
