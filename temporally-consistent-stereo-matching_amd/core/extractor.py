@@ -1,9 +1,9 @@
 """Feature / context extractors (reference: core/extractor.py): the same module tree, so that the reference's
 checkpoints load with strict=True (same attribute names, same parameter shapes).  BASELINE.json's north_star leaves
-the extractor on PyTorch-ROCm; the 7x7 RGB stem and the batch/group-norm variants do stay there (MIOpen), but the
-3x3 / 1x1 trunk of the `none` and `instance` norm configurations runs on tcs_conv2d like the refinement loop: on
-these shapes the fp16-split kernel is 2-2.5x faster than MIOpen's fp32 solvers (tools/bench_extractor_convs.py) and
-the ReLU / residual-add tails are fused into its epilogue."""
+the extractor on PyTorch-ROCm; the batch/group-norm variants do stay there, but the whole `none` / `instance` norm
+configuration (7x7 RGB stem, 3x3 / 1x1 trunk, heads) runs on tcs_conv2d like the refinement loop: on these shapes the
+fp16-split kernel is 2-2.5x faster than MIOpen's fp32 solvers (tools/bench_extractor_convs.py) and the ReLU / residual-add
+tails are fused into its epilogue; no MIOpen kernel is left in the steady-state trace of the shipped configuration."""
 import torch
 import torch.nn as nn
 
@@ -81,6 +81,20 @@ def _hip_trunk() -> bool:
     return os.environ.get("TCS_MI355_EXTRACTOR", "hip") != "torch"
 
 
+def hip_stem(enc, x):
+    """relu(norm1(conv1(x))): the 7x7 RGB stem (extractor.py:205-207,270-272).  Stride 1 with `none` / `instance` norm runs on
+    tcs_conv2d's 7x7 kernel (ReLU fused) and k_instance_norm; other settings (stride-2 stem, batch / group norm) stay on PyTorch."""
+    kind = enc.norm_fn
+    if x.is_cuda and _hip_trunk() and enc.conv1.stride == (1, 1) and kind in ("none", "instance"):
+        from core.update import packed
+        x = x.float().contiguous()
+        pc = packed(enc.conv1)              # 7x7: pack_conv keeps the fp32 layout
+        if kind == "none":
+            return ops.conv2d(pc, [x], act="relu")
+        return ops.instance_norm(ops.conv2d(pc, [x]), act="relu")
+    return enc.relu1(enc.norm1(enc.conv1(x)))
+
+
 def hip_head(f, x):
     """An output head: Conv2d, or Sequential(ResidualBlock, Conv2d) (extractor.py:221-238)."""
     if not (x.is_cuda and _hip_trunk()):
@@ -118,7 +132,7 @@ class BasicEncoder(nn.Module):
         if isinstance(x, (tuple, list)):
             parts = x[0].shape[0]
             x = torch.cat(x, 0)
-        x = self.relu1(self.norm1(self.conv1(x)))
+        x = hip_stem(self, x)
         x = hip_head(self.conv2, self.layer3(self.layer2(self.layer1(x))))
         if self.training and self.dropout is not None:
             x = self.dropout(x)
@@ -152,7 +166,7 @@ class MultiBasicEncoder(nn.Module):
         _init(self, "fan_out")
 
     def forward(self, x, dual_inp=False, num_layers=3):
-        x = self.relu1(self.norm1(self.conv1(x)))
+        x = hip_stem(self, x)
         x = self.layer3(self.layer2(self.layer1(x)))
         tail = ()
         if dual_inp:

@@ -200,39 +200,45 @@ __global__ __launch_bounds__(256) void k_conv_cin1(ConvArgs a) {
     cin1_store16(a, b, co_lo, y, x, p, HW, acc);
 }
 
-// 7x7 stem on a 1-channel input (BasicMotionEncoder.convf1, update.py:113): 64 x 4 pixel tile per block, the tile
-// (+3 halo) and the block's 49 x 16 weights live in LDS, the filter rows run as a rolled loop so that nothing spills
-// (fully unrolled, the 196 weight reads were hoisted and spilled to scratch).
-__global__ __launch_bounds__(256) void k_conv7x7_cin1(ConvArgs a) {
+// 7x7 stems: CIN = 1 (BasicMotionEncoder.convf1 on the flow, update.py:113) and CIN = 3 (the RGB stems of the feature /
+// context encoders, extractor.py:205,270: the last layer that ran on MIOpen).  K = 49*CIN is small and the tile-halo ratio of
+// a 7x7 window is poor for the 32-pixel MFMA tiles, so this is a plain fp32 FMA kernel (bit-for-bit an fmaf chain like the
+// reference's CPU convolution up to summation order): 64 x 4 pixel tile per block, the tile (+3 halo) of every input channel and
+// the block's 49*CIN x 16 weights live in LDS, the filter rows run as a rolled loop so that nothing spills (fully unrolled, the
+// weight reads were hoisted and spilled to scratch).  16 output channels per blockIdx.z.
+template <int CIN>
+__global__ __launch_bounds__(256) void k_conv7x7(ConvArgs a) {
     constexpr int KS = 7, HALO = 3, TW = 64, TH = 4, IW = TW + 2 * HALO, IH = TH + 2 * HALO;
-    __shared__ float s_in[IH * IW];
-    __shared__ __attribute__((aligned(16))) float s_w[KS * KS * 16];
+    __shared__ float s_in[CIN * IH * IW];
+    __shared__ __attribute__((aligned(16))) float s_w[CIN * KS * KS * 16];
     const int b = blockIdx.y, H = a.H, W = a.W, HW = H * W;
     const int ntx = (W + TW - 1) / TW;
     const int tx0 = (blockIdx.x % ntx) * TW, ty0 = (blockIdx.x / ntx) * TH;
     const int co_lo = blockIdx.z * 16;
-    const float* s = a.src[0] + (size_t)b * HW;
-    for (int i = threadIdx.x; i < IH * IW; i += 256) {
-        const int r = i / IW, c = i - r * IW;
+    const float* s = a.src[0] + (size_t)b * CIN * HW;
+    for (int i = threadIdx.x; i < CIN * IH * IW; i += 256) {
+        const int ci = i / (IH * IW), q = i - ci * (IH * IW);
+        const int r = q / IW, c = q - r * IW;
         const int yy = ty0 - HALO + r, xx = tx0 - HALO + c;
         const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-        const float v = s[min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)];
+        const float v = s[(size_t)ci * HW + min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)];
         s_in[i] = ok ? v : 0.f;
     }
-    for (int i = threadIdx.x; i < KS * KS * 16; i += 256) s_w[i] = a.w[(size_t)(i >> 4) * a.CoutPad + co_lo + (i & 15)];
+    for (int i = threadIdx.x; i < CIN * KS * KS * 16; i += 256) s_w[i] = a.w[(size_t)(i >> 4) * a.CoutPad + co_lo + (i & 15)];
     __syncthreads();
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
     float acc[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) acc[c] = 0.f;
 #pragma unroll 1
-    for (int ty = 0; ty < KS; ++ty) {
+    for (int ct = 0; ct < CIN * KS; ++ct) {                  // (input channel, filter row)
+        const int ci = ct / KS, ty = ct - ci * KS;
 #pragma unroll
         for (int tx = 0; tx < KS; ++tx) {
-            const float v = s_in[(ly + ty) * IW + lx + tx];
+            const float v = s_in[(ci * IH + ly + ty) * IW + lx + tx];
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) {
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(&s_w[(ty * KS + tx) * 16 + c4 * 4]);
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(&s_w[((ci * KS + ty) * KS + tx) * 16 + c4 * 4]);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[c4 * 4 + c] = fmaf(w4[c], v, acc[c4 * 4 + c]);
             }
@@ -363,13 +369,18 @@ int tcs_conv2d(const tcs_conv_desc* d, tcs_stream_t stream) {
             else if (d->ksize == 3) hipLaunchKernelGGL(k_conv_cin1<3>, grid, dim3(256), 0, s, a);
             else if (d->ksize == 7) {
                 const dim3 g7(tcs_cdiv(d->W, 64) * tcs_cdiv(d->H, 4), d->B, tcs_cdiv(d->Cout, 16));
-                hipLaunchKernelGGL(k_conv7x7_cin1, g7, dim3(256), 0, s, a);
+                hipLaunchKernelGGL(k_conv7x7<1>, g7, dim3(256), 0, s, a);
             }
             else return TCS_EUNSUPPORTED;
             return tcs_launch_status();
         }
         if (d->ksize == 3) return launch_by_tile<3, TCS_EPI_LINEAR>(a, nt, s);
         if (d->ksize == 1) return launch_by_tile<1, TCS_EPI_LINEAR>(a, nt, s);
+        if (d->ksize == 7 && d->Cin == 3 && d->n_src == 1 && d->act != TCS_ACT_RELU_ADD_RELU) {   // RGB stem
+            const dim3 g7(tcs_cdiv(d->W, 64) * tcs_cdiv(d->H, 4), d->B, tcs_cdiv(d->Cout, 16));
+            hipLaunchKernelGGL(k_conv7x7<3>, g7, dim3(256), 0, s, a);
+            return tcs_launch_status();
+        }
         return TCS_EUNSUPPORTED;
     }
     // GRU epilogues: hidden = Cout/2 (ZR) or Cout (Q); tiles must not straddle the z|r boundary

@@ -261,6 +261,7 @@ def test_stencils_golden(dev, ops_golden, model):
     dict(B=2, cins=(36,), cout=64, k=1, H=9, W=37),                    # convc1-like, ragged size, batch 2
     dict(B=1, cins=(64, 64), cout=127, k=3, H=8, W=24),                # encoder.conv: 127 outputs
     dict(B=1, cins=(1,), cout=64, k=7, H=10, W=33),                    # convf1: single input channel
+    dict(B=2, cins=(3,), cout=64, k=7, H=13, W=70),                    # the extractors' 7x7 RGB stem (extractor.py:205,270)
     dict(B=1, cins=(27,), cout=96, k=1, H=7, W=65),                    # disp_f_stem: 27 inputs
     dict(B=1, cins=(256,), cout=1, k=3, H=6, W=32),                    # flow head conv2
     dict(B=1, cins=(128,), cout=384, k=3, H=30, W=40),                 # context_zqr conv: 3 cout tiles
