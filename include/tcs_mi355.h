@@ -305,13 +305,16 @@ typedef struct tcs_conv_s16_desc {
     const float* bias;       /* [Cout] or NULL */
     int B, H, W;             /* INPUT grid */
     int Cin, Cout, ksize;    /* ksize in {1,3} */
-    int stride;              /* 1, or 2 (3x3 pad 1, LINEAR): output (H-1)/2+1 x (W-1)/2+1 */
+    int stride;              /* 1, or 2 (3x3 pad 1 or 1x1 pad 0, LINEAR): output (H-1)/2+1 x (W-1)/2+1 */
     int epilogue;            /* TCS_EPI_* as for tcs_conv2d */
     int act;
     float post_scale;
     float weight_unscale;
     const float* addend;     /* fp32 NCHW: LINEAR addend [B,Cout,Ho,Wo]; GRU_ZR cz / GRU_Q cq [B,hidden,H,W] (nullable) */
     const float* addend2;    /* GRU_ZR: cr */
+    const void* addend16;    /* LINEAR: S16 addend on the output grid (the skip of a residual block, extractor.py:44-58; use with
+                                TCS_ACT_RELU_ADD_RELU), addend16_groups groups; nullable */
+    int addend16_groups;
     const void* h;           /* GRU: hidden state, S16 with h_groups groups */
     int h_groups;
     const float* z;          /* GRU_Q: update gate, fp32 [B,hidden,H,W] */

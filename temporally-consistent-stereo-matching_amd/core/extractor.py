@@ -7,7 +7,7 @@ tails are fused into its epilogue; no MIOpen kernel is left in the steady-state 
 import torch
 import torch.nn as nn
 
-from tcs_mi355 import ops
+from tcs_mi355 import ops, s16
 
 
 def _norm(kind, ch, stem=False):
@@ -54,6 +54,24 @@ class ResidualBlock(nn.Module):
         skip = x if self.downsample is None else self.downsample(x)
         return self.relu(skip + y)
 
+    def run16(self, pool, x: "s16.S16") -> "s16.S16":
+        """The block on pre-split (S16) tensors (tcs_conv2d_s16; `none` / `instance` norm): conv -> [IN] -> ReLU -> conv -> [IN] -> ReLU,
+        + skip, ReLU, with the tails in the convolution / InstanceNorm epilogues; the projection shortcut is a 1x1 (stride s) conv."""
+        from core.update import conv16
+        inorm = self.norm_kind == "instance"
+        skip = x
+        if self.downsample is not None:
+            skip = conv16(pool, self.downsample[0], [x])
+            if inorm:
+                skip = s16.instance_norm(skip, out=skip)
+        if not inorm:
+            y = conv16(pool, self.conv1, [x], act="relu")
+            return conv16(pool, self.conv2, [y], act="relu_add_relu", addend16=skip)
+        y = conv16(pool, self.conv1, [x])
+        y = s16.instance_norm(y, act="relu", out=y)
+        z = conv16(pool, self.conv2, [y])
+        return s16.instance_norm(z, act="relu_add_relu", addend=skip, out=z)
+
     def _forward_hip(self, x):
         """relu(skip + relu(norm2(conv2(relu(norm1(conv1(x))))))) (extractor.py:44-58) in 2-6 launches."""
         from core.update import hip_conv, packed
@@ -95,8 +113,28 @@ def hip_stem(enc, x):
     return enc.relu1(enc.norm1(enc.conv1(x)))
 
 
+def _s16_ok(kind: str, hw: int) -> bool:
+    """S16 trunk: `none` norm anywhere, `instance` norm on planes the S16 InstanceNorm kernels are sized for (<= 1/4 scale)."""
+    return kind == "none" or (kind == "instance" and hw <= 40960)
+
+
+def hip_head16(pool, f, x: "s16.S16") -> torch.Tensor:
+    """An output head on an S16 trunk tensor -> fp32 NCHW (what the correlation build / context convolutions consume)."""
+    from core.update import conv16
+    if isinstance(f, nn.Sequential):
+        for m in f:
+            if isinstance(m, nn.Conv2d):
+                return conv16(pool, m, [x], want32=True)
+            x = m.run16(pool, x)
+        raise ValueError("head without a final convolution")
+    return conv16(pool, f, [x], want32=True)
+
+
 def hip_head(f, x):
-    """An output head: Conv2d, or Sequential(ResidualBlock, Conv2d) (extractor.py:221-238)."""
+    """An output head: Conv2d, or Sequential(ResidualBlock, Conv2d) (extractor.py:221-238); `x` may be an S16 trunk tensor."""
+    if isinstance(x, s16.S16):
+        from core.update import pool_of
+        return hip_head16(pool_of(f), f, x)
     if not (x.is_cuda and _hip_trunk()):
         return f(x)
     from core.update import hip_conv
@@ -165,7 +203,36 @@ class MultiBasicEncoder(nn.Module):
         self.dropout = nn.Dropout2d(p=dropout) if dropout > 0 else None
         _init(self, "fan_out")
 
+    def _forward16(self, x, dual_inp, num_layers):
+        """`none`-norm context network end to end on pre-split tensors: the stem writes S16, every residual block stays S16, only
+        the heads' final convolutions produce fp32.  With `dual_inp` the trunk (an S16 tensor) is returned last, for the matching-feature head."""
+        from core.update import conv32to16, pool_of
+        pool = pool_of(self)
+        x = conv32to16(pool, self.conv1, x.float().contiguous(), act="relu")                       # 7x7 stem, S16 epilogue
+        for layer in (self.layer1, self.layer2, self.layer3):
+            for blk in layer:
+                x = blk.run16(pool, x)
+        tail = ()
+        if dual_inp:
+            tail = (x,)
+            x = s16.S16(x.data[: x.B // 2], x.C)                                                    # left images only (batch-major layout)
+        scales = [[hip_head16(pool, f, x) for f in self.outputs08]]
+        if num_layers >= 2:
+            y = x
+            for blk in self.layer4:
+                y = blk.run16(pool, y)
+            scales.append([hip_head16(pool, f, y) for f in self.outputs16])
+        if num_layers >= 3:
+            z = y
+            for blk in self.layer5:
+                z = blk.run16(pool, z)
+            scales.append([hip_head16(pool, f, z) for f in self.outputs32])
+        return (*scales, *tail)
+
     def forward(self, x, dual_inp=False, num_layers=3):
+        from core.update import _X
+        if x.is_cuda and _hip_trunk() and self.norm_fn == "none" and self.conv1.stride == (1, 1) and "noext16" not in _X:
+            return self._forward16(x, dual_inp, num_layers)
         x = hip_stem(self, x)
         x = self.layer3(self.layer2(self.layer1(x)))
         tail = ()

@@ -91,7 +91,8 @@ class TCStereo(nn.Module):
         a = self.args
         if a.shared_backbone:
             *cnet_list, trunk = self.cnet(torch.cat((image1, image2), 0), dual_inp=True, num_layers=a.n_gru_layers)
-            fmap1, fmap2 = hip_head(self.conv2, trunk).split(trunk.shape[0] // 2, 0)
+            fm = hip_head(self.conv2, trunk)                     # trunk: fp32 tensor, or an S16 tensor from the all-HIP context network
+            fmap1, fmap2 = fm.split(fm.shape[0] // 2, 0)
         else:
             cnet_list = self.cnet(image1, num_layers=a.n_gru_layers)
             fmap1, fmap2 = self.fnet([image1, image2])

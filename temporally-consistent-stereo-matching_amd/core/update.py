@@ -76,7 +76,7 @@ def pool_of(module) -> s16.S16Pool:
 _X = set(t for t in os.environ.get("TCS_MI355_X", "").split(",") if t)
 
 
-def conv16(pool, conv, srcs, act="none", addend=None, post_scale=1.0, out=None, want32=False, tag="o"):
+def conv16(pool, conv, srcs, act="none", addend=None, post_scale=1.0, out=None, want32=False, tag="o", addend16=None):
     """A Conv2d on S16 sources -> S16 (a pool buffer owned by this conv, or `out`), or fp32 NCHW when want32."""
     a = srcs[0]
     stride = conv.stride[0]
@@ -85,10 +85,12 @@ def conv16(pool, conv, srcs, act="none", addend=None, post_scale=1.0, out=None, 
     if "t2" in _X and conv.kernel_size[0] == 3 and stride == 1 and a.H * a.W >= 10000:
         tc = 101812                      # A/B: two-stage 8-row tiles on every 1/4-scale 3x3 layer
     if want32:
-        return s16.conv2d(packed16(conv), srcs, act=act, addend=addend, post_scale=post_scale, want32=True, stride=stride, tile_cfg=tc)[1]
+        return s16.conv2d(packed16(conv), srcs, act=act, addend=addend, post_scale=post_scale, want32=True, stride=stride, tile_cfg=tc,
+                          addend16=addend16)[1]
     if out is None:
         out = pool.get((id(conv), tag), a.B, conv.out_channels, Ho, Wo, a.device)
-    return s16.conv2d(packed16(conv), srcs, act=act, addend=addend, post_scale=post_scale, out16=out, stride=stride, tile_cfg=tc)[0]
+    return s16.conv2d(packed16(conv), srcs, act=act, addend=addend, post_scale=post_scale, out16=out, stride=stride, tile_cfg=tc,
+                      addend16=addend16)[0]
 
 
 def conv32to16(pool, conv, x, act="none", tag="o"):

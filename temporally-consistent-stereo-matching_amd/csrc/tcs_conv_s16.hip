@@ -45,6 +45,8 @@ struct S16Args {
     float post_scale, w_unscale;
     const float* add1;                  // fp32 NCHW addends ([B][Cout or hidden][H][W])
     const float* add2;
+    const _Float16* add16;              // LINEAR: S16 addend (residual skip), add16_groups groups
+    int add16_groups;
     const _Float16* h;                  // GRU: hidden state, S16 [B][h_groups][2][H+2][W+2][8]
     int h_groups;
     const float* z;                     // GRU_Q: update gate, fp32 NCHW
@@ -85,15 +87,28 @@ __device__ __forceinline__ void s16_epilogue_tile(const S16Args& a, int b, int c
     }
     const int sub4 = co0 & 4;                        // this lane half's 4-channel slot inside a group
     if (EPI == TCS_EPI_LINEAR) {
+        const bool late = a.act == TCS_ACT_RELU_ADD_RELU;          // relu(relu(v) + addend): the tail of a residual block
         if (a.add1) {
             float t[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) t[r] = a.add1[((size_t)b * a.Cout + cc[r]) * HW + pix];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] += t[r];
+            for (int r = 0; r < 16; ++r) v[r] = (late ? fmaxf(v[r], 0.f) : v[r]) + t[r];
         }
+        if (a.add16) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = ok[r] ? apply_act(v[r], a.act) * a.post_scale : 0.f;
+            for (int q = 0; q < 4; ++q) {
+                const int gq = min((co0 >> 3) + q, a.add16_groups - 1);
+                const _Float16* ap = a.add16 + s16_unit(b, a.add16_groups, gq, 0, Hp, Wp, py, px) + sub4;
+                const half4 hi = *reinterpret_cast<const half4*>(ap);
+                const half4 lo = *reinterpret_cast<const half4*>(ap + (size_t)Hp * Wp * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[4 * q + j] = (late ? fmaxf(v[4 * q + j], 0.f) : v[4 * q + j]) + (float)hi[j] + (float)lo[j];
+            }
+        }
+        const int act = late ? TCS_ACT_RELU : a.act;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = ok[r] ? apply_act(v[r], act) * a.post_scale : 0.f;
         if (a.out32) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -499,6 +514,11 @@ static int launch_s16_cfg(S16Args& a, int cfg, hipStream_t s) {
             S16_CASE(1, 4, 1, 2)
             default: return TCS_EUNSUPPORTED;
         }
+    } else if constexpr (STRIDE == 2) {                 // 1x1 stride 2 (the projection shortcut of a down-sampling residual block)
+        switch (cfg) {
+            S16_CASE(1, 4, 1, 2) S16_CASE(1, 4, 2, 2)
+            default: return TCS_EUNSUPPORTED;
+        }
     } else {
         switch (cfg) {
             S16_CASE(1, 4, 1, 2) S16_CASE(2, 4, 1, 2)
@@ -517,6 +537,7 @@ static int launch_s16_cfg(S16Args& a, int cfg, hipStream_t s) {
 //  * 1x1: two k-steps per stage; 64-channel tiles for Cout >= 256;
 //  * CSPLIT = 1 (all cout tiles of a patch on one XCD, s16_block_tile): 0-3 % on 3x3, 20-30 % on the 1x1 layers.
 static int s16_heuristic(const S16Args& a, int ksize, int stride, int kst1x1) {
+    if (ksize == 1 && stride == 2) return 1000 + 400 + kst1x1 * 10 + 2;
     if (ksize == 1) {
         const int mt = (a.nct32 % 2 == 0 && a.nct32 >= 8) ? 2 : 1;
         return 100000 + mt * 1000 + 400 + kst1x1 * 10 + 2;
@@ -567,7 +588,7 @@ int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
     if (d->B <= 0 || d->B > 65535 || d->H <= 0 || d->W <= 0 || d->Cout <= 0) return TCS_EINVAL;
     if (d->ksize != 1 && d->ksize != 3) return TCS_EUNSUPPORTED;
     const int stride = d->stride == 2 ? 2 : 1;
-    if (stride == 2 && (d->ksize != 3 || d->epilogue != TCS_EPI_LINEAR)) return TCS_EUNSUPPORTED;
+    if (stride == 2 && d->epilogue != TCS_EPI_LINEAR) return TCS_EUNSUPPORTED;
     S16Args a;
     int ktot = 0, cin = 0;
     for (int i = 0; i < TCS_MAX_SRC; ++i) {
@@ -592,6 +613,9 @@ int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
     a.Cout = d->Cout; a.nct32 = (d->Cout + 31) / 32;
     a.act = d->act; a.post_scale = d->post_scale; a.w_unscale = d->weight_unscale;
     a.add1 = d->addend; a.add2 = d->addend2;
+    a.add16 = reinterpret_cast<const _Float16*>(d->addend16); a.add16_groups = d->addend16_groups;
+    if (a.add16 && (d->epilogue != TCS_EPI_LINEAR || a.add16_groups < (d->Cout + 7) / 8)) return TCS_EINVAL;
+    if (d->act == TCS_ACT_RELU_ADD_RELU && !a.add16 && !a.add1) return TCS_EINVAL;
     a.h = reinterpret_cast<const _Float16*>(d->h); a.h_groups = d->h_groups; a.z = d->z;
     a.keep_z = d->blend_keep_z; a.hidden = 0;
     a.out16 = reinterpret_cast<_Float16*>(d->out16); a.out16_groups = d->out16_groups; a.out16_goff = d->out16_group_offset;
@@ -600,7 +624,6 @@ int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
     a.csplit = (d->tile_cfg / 100000) % 10;            // 0 = cout tile fastest (one weight slice per XCD)
     a.ablate = d->tile_cfg / 1000000;                  // honoured by -DTCS_S16_ABLATE builds only
     if (!a.out16 && !a.out32) return TCS_EINVAL;
-    if (a.act == TCS_ACT_RELU_ADD_RELU) return TCS_EUNSUPPORTED;
     // the packed weight image pads K to a multiple of 64 channels (tcs_conv_packed_floats_f16x3): nk may not exceed it
     const int kpack = ((d->Cin + 63) / 64) * 4;
     int kst = 1;
@@ -636,6 +659,7 @@ int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
 
     switch (d->epilogue) {
         case TCS_EPI_LINEAR:
+            if (stride == 2 && d->ksize == 1) return launch_s16_cfg<1, 2, TCS_EPI_LINEAR>(a, cfg, s);
             if (stride == 2) return launch_s16_cfg<3, 2, TCS_EPI_LINEAR>(a, cfg, s);
             return d->ksize == 3 ? launch_s16_cfg<3, 1, TCS_EPI_LINEAR>(a, cfg, s) : launch_s16_cfg<1, 1, TCS_EPI_LINEAR>(a, cfg, s);
         case TCS_EPI_DECONV2X:

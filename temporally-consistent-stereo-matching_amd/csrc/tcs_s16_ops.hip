@@ -129,6 +129,7 @@ __global__ __launch_bounds__(INS_T) void k_in_stats_s16(const _Float16* __restri
 __device__ __forceinline__ float s16_act(float v, int act) {
     switch (act) {
         case TCS_ACT_RELU: return fmaxf(v, 0.f);
+        case TCS_ACT_RELU_ADD_RELU: return fmaxf(v, 0.f);          // the outer ReLU is applied after the addend (k_in_apply_s16)
         case TCS_ACT_LEAKY: return v > 0.f ? v : 0.01f * v;
         default: return v;
     }
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(INS_T) void k_in_apply_s16(const _Float16* __restri
     for (int j = 0; j < 8; ++j) {
         const float rstd = 1.0f / sqrtf(m2[j] / (float)HW + eps);
         v[j] = s16_act((v[j] - mean[j]) * rstd, act) + (addend ? t[j] : 0.f);
+        if (act == TCS_ACT_RELU_ADD_RELU) v[j] = fmaxf(v[j], 0.f);       // relu(relu(norm(x)) + skip), extractor.py:44-58
     }
     s16_store8(out + (((size_t)b * Go + g) * 2) * plane + u, plane, v);
 }
@@ -261,7 +263,8 @@ int tcs_instance_norm_s16(const void* x, int B, int groups, int H, int W, float 
                           void* out, int out_groups, void* workspace, tcs_stream_t stream) {
     if (!x || !out || !workspace || B <= 0 || groups <= 0 || out_groups < groups || H <= 0 || W <= 0 || eps < 0.f) return TCS_EINVAL;
     if (addend && addend_groups < groups) return TCS_EINVAL;
-    if (act != TCS_ACT_NONE && act != TCS_ACT_RELU && act != TCS_ACT_LEAKY) return TCS_EUNSUPPORTED;
+    if (act != TCS_ACT_NONE && act != TCS_ACT_RELU && act != TCS_ACT_LEAKY && act != TCS_ACT_RELU_ADD_RELU) return TCS_EUNSUPPORTED;
+    if (act == TCS_ACT_RELU_ADD_RELU && !addend) return TCS_EINVAL;
     if ((long long)B * groups > 65535) return TCS_EUNSUPPORTED;
     if (out_groups != groups || (addend && addend_groups != groups)) return TCS_EUNSUPPORTED;   // same-shape tensors only
     const int HW = H * W, nsl = tcs_cdiv(HW, INS_T * INS_UPT), slice = tcs_cdiv(HW, nsl);

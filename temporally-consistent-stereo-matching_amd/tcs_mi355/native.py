@@ -47,7 +47,7 @@ class ConvS16Desc(C.Structure):
         ("B", c_int), ("H", c_int), ("W", c_int),
         ("Cin", c_int), ("Cout", c_int), ("ksize", c_int), ("stride", c_int),
         ("epilogue", c_int), ("act", c_int), ("post_scale", c_f), ("weight_unscale", c_f),
-        ("addend", c_fp), ("addend2", c_fp), ("h", c_fp), ("h_groups", c_int), ("z", c_fp),
+        ("addend", c_fp), ("addend2", c_fp), ("addend16", c_fp), ("addend16_groups", c_int), ("h", c_fp), ("h_groups", c_int), ("z", c_fp),
         ("blend_keep_z", c_int),
         ("out16", c_fp), ("out16_groups", c_int), ("out16_group_offset", c_int),
         ("out32", c_fp), ("out_ctot", c_int), ("out_coff", c_int),

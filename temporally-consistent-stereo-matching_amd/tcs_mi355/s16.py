@@ -143,7 +143,7 @@ def _out_grid(s: S16, stride: int):
 
 def conv2d(pc: PackedConv, srcs: Sequence[S16], act: str = "none", addend: Optional[torch.Tensor] = None, post_scale: float = 1.0,
            out16: Optional[S16] = None, out16_group_offset: int = 0, out32: Optional[torch.Tensor] = None, out_coff: int = 0,
-           stride: int = 1, want32: bool = False, tile_cfg: int = 0):
+           stride: int = 1, want32: bool = False, tile_cfg: int = 0, addend16: Optional[S16] = None):
     """act(conv(cat(srcs)) + bias + addend) * post_scale -> S16 (`out16`, allocated when neither output is given)
     and/or fp32 NCHW (`out32`, or allocated when want32).  Returns (out16, out32)."""
     d = _desc(pc, srcs, stride)
@@ -160,6 +160,10 @@ def conv2d(pc: PackedConv, srcs: Sequence[S16], act: str = "none", addend: Optio
         raise ValueError("conv2d: bad addend shape")
     d.epilogue, d.act, d.post_scale = EPI_LINEAR, ACT[act], float(post_scale)
     d.addend = nv.ptr(addend, "addend")
+    if addend16 is not None:
+        if (addend16.B, addend16.H, addend16.W) != (d.B, Ho, Wo):
+            raise ValueError("conv2d: bad addend16 grid")
+        d.addend16, d.addend16_groups = addend16.ptr(), addend16.G
     if out16 is not None:
         d.out16, d.out16_groups, d.out16_group_offset = out16.ptr(), out16.G, int(out16_group_offset)
     if out32 is not None:

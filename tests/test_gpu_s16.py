@@ -91,6 +91,37 @@ def test_conv2d_s16_vs_torch(dev, cfg):
         assert maxdiff(s16.conv2d(pc, xs16, act=act, stride=stride)[0].float(), fn(ref)) <= 2e-5
 
 
+def test_conv2d_s16_residual_block_pieces(dev):
+    """The residual blocks of the feature extractor on S16 tensors (extractor.py:37-57): relu(skip + relu(conv(y))) with the
+    skip read as an S16 addend, the 1x1 stride-2 shortcut, and the instance-norm variant relu(skip + relu(IN(z)))."""
+    from tcs_mi355 import ops, s16
+    gen = torch.Generator().manual_seed(17)
+    for B, C_, H, W in ((1, 64, 11, 37), (2, 96, 8, 24)):
+        w = torch.randn(C_, C_, 3, 3, generator=gen) * (2.0 / (9 * C_)) ** 0.5
+        b = torch.randn(C_, generator=gen) * 0.1
+        y, skip = torch.randn(B, C_, H, W, generator=gen), torch.randn(B, C_, H, W, generator=gen)
+        ref = torch.relu(skip.double() + torch.relu(F.conv2d(y.double(), w.double(), b.double(), padding=1)))
+        pc = ops.pack_conv(D(w, dev), D(b, dev), "f16x3")
+        for tc in (0, 1412, 101812):
+            got, _ = s16.conv2d(pc, [s16.to_s16(D(y, dev))], act="relu_add_relu", addend16=s16.to_s16(D(skip, dev)), tile_cfg=tc)
+            assert maxdiff(got.float(), ref) <= 2e-5, (C_, tc)
+        # plain S16 addend with a linear epilogue
+        got, _ = s16.conv2d(pc, [s16.to_s16(D(y, dev))], act="relu", addend16=s16.to_s16(D(skip, dev)))
+        assert maxdiff(got.float(), torch.relu(F.conv2d(y.double(), w.double(), b.double(), padding=1) + skip.double())) <= 2e-5
+        # downsample shortcut: 1x1, stride 2, ragged grid
+        wd = torch.randn(C_ + 32, C_, 1, 1, generator=gen) * (1.0 / C_) ** 0.5
+        bd = torch.randn(C_ + 32, generator=gen) * 0.1
+        got, _ = s16.conv2d(ops.pack_conv(D(wd, dev), D(bd, dev), "f16x3"), [s16.to_s16(D(y, dev))], stride=2)
+        assert (got.H, got.W) == ((H + 1) // 2, (W + 1) // 2)
+        assert maxdiff(got.float(), F.conv2d(y.double(), wd.double(), bd.double(), stride=2)) <= 2e-5
+        # instance-norm residual epilogue
+        z = torch.randn(B, C_, H, W, generator=gen) * 2 + 0.5
+        refn = torch.relu(skip.double() + torch.relu(F.instance_norm(z.double(), eps=1e-5)))
+        z16 = s16.to_s16(D(z, dev))
+        s16.instance_norm(z16, act="relu_add_relu", addend=s16.to_s16(D(skip, dev)), out=z16)
+        assert maxdiff(z16.float(), refn) <= 1e-5
+
+
 def test_conv2d_s16_partial_store_keeps_foreign_channel(dev):
     """encoder.conv writes 127 channels into the 128-channel motion buffer whose channel 127 belongs to the blend kernel."""
     from tcs_mi355 import ops, s16
