@@ -327,6 +327,12 @@ typedef struct tcs_conv_s16_desc {
     int out_ctot, out_coff;
     int tile_cfg;            /* 0 = choose by grid size; otherwise CSPLIT*100000 + RS*10000 + MT*1000 + ROWS*100 + KSTEPS*10 + NSTAGE
                                 (benchmarks, tests; csrc/tcs_conv_s16.hip) */
+    int addend_ctot;         /* channels per batch element of `addend` / `addend2` (0 = Cout, or hidden for the GRU epilogues).  A wider
+                                value lets them be channel slices of one tensor: a convolution is linear in its input channels, so a
+                                layer whose inputs become available at different times runs as partial convolutions that
+                                accumulate into one fp32 [B, addend_ctot, H, W] tensor (LINEAR: addend = out32), and the last
+                                partial applies the real epilogue with that sum as its addend (GRU_ZR: cz = sum[:, :hidden],
+                                cr = sum[:, hidden:]) */
 } tcs_conv_s16_desc;
 
 /* S16 glue of the loop: pool2x / interp (core/update.py:114-124), the up-blocks' InstanceNorm + LeakyReLU + skip

@@ -185,6 +185,7 @@ class TCStereo(nn.Module):
                 for i, t in enumerate(net_list)]
         grads16 = [s16.to_s16(t.float().contiguous(), out=pool.get(("frame", "ctxg", i), t.shape[0], t.shape[1], t.shape[2], t.shape[3], t.device))
                    for i, t in enumerate(grad_list)]
+        dg_pre = self.disp_grad_refine.prepare(pool, grads16)      # the context share of three convolutions: once per frame
         refined = up_mask = None
         # coords1 - coords0, the motion encoder's flow input (tc_stereo.py:180): once here, afterwards the blend kernel writes
         # it for the next iteration — as a tensor for the 7x7 stem and into channel 127 of the motion feature buffer
@@ -223,11 +224,16 @@ class TCStereo(nn.Module):
             # disp_q = x - (coords1 + delta), 5 * disp2disp_gradient_xy (update.py:199) and the gradient candidates in one
             # launch; coords1 is replaced by the blend kernel's output below
             disp_q, g5, cands = ops.flow_step_grads(coords1, delta_flow, scale=5.0)
-            disp_grad, context = self.disp_grad_refine.run(pool, g5, cands, grads16)
+            disp_grad, context = self.disp_grad_refine.run(pool, g5, cands, dg_pre)
             last = itr == iters - 1
             refined, up_mask, fused = self.disp_refine.run(pool, disp_grad, disp_q, nets[0], context, want_mask=last, motion=motion)
             hu_delta = fused["delta_disp"]
             coords1, flows_x = fused["coords1"], fused["flow_x"]
+            sums = getattr(self, "_checksums", None)       # debugging hook (tools/determinism_check.py): device-side sums, no sync
+            if sums is not None:
+                sums.append({k: v.double().sum() for k, v in dict(
+                    corr=corr, motion=m.data, net0=nets[0].data, net1=nets[1].data, net2=nets[2].data, delta_flow=delta_flow,
+                    disp_grad=disp_grad, context=context.data, refined=refined, coords1=coords1).items()})
             if trace is not None:
                 self.hiddenstate_update.run(pool, nets[0], hu_delta)       # debugging hook: states as of the end of the iteration
                 hu_delta = None

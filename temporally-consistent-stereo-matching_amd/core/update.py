@@ -62,6 +62,22 @@ def packed16(conv: nn.Conv2d) -> ops.PackedConv:
     return packed(conv)
 
 
+def packed16_part(conv: nn.Conv2d, cin_slices, with_bias: bool = True) -> ops.PackedConv:
+    """fp16-split packing of `conv.weight[:, cat(cin_slices)]` (with or without the bias): one K-slice of a layer.  A
+    convolution is linear in its input channels, so a layer over cat(a, b) whose inputs are ready at different times runs as
+    conv_a(a) + bias -> fp32 partial sum, then conv_b(b) with that sum as the epilogue's addend (tcs_mi355.h, addend_ctot)."""
+    w, b = conv.weight, conv.bias
+    key = (w.data_ptr(), w._version, w.device, None if b is None else (b.data_ptr(), b._version))
+    cache = conv.__dict__.setdefault("_tcs_parts", {})
+    spec = (tuple(tuple(int(v) for v in sl) for sl in cin_slices), bool(with_bias))
+    hit = cache.get(spec)
+    if hit is None or hit[0] != key:
+        ws = torch.cat([w.detach()[:, lo:hi] for lo, hi in spec[0]], 1).contiguous()
+        hit = (key, ops.pack_conv(ws, b if with_bias else None, "f16x3"))
+        cache[spec] = hit
+    return hit[1]
+
+
 def pool_of(module) -> s16.S16Pool:
     """The S16 buffer pool of the model a module belongs to (TCStereo shares one; a stand-alone module gets its own)."""
     p = getattr(module, "_s16pool", None)
@@ -76,20 +92,22 @@ def pool_of(module) -> s16.S16Pool:
 _X = set(t for t in os.environ.get("TCS_MI355_X", "").split(",") if t)
 
 
-def conv16(pool, conv, srcs, act="none", addend=None, post_scale=1.0, out=None, want32=False, tag="o", addend16=None):
-    """A Conv2d on S16 sources -> S16 (a pool buffer owned by this conv, or `out`), or fp32 NCHW when want32."""
+def conv16(pool, conv, srcs, act="none", addend=None, post_scale=1.0, out=None, want32=False, tag="o", addend16=None, pc=None):
+    """A Conv2d on S16 sources -> S16 (a pool buffer owned by this conv, or `out`), or fp32 NCHW when want32.
+    `pc`: a K-slice of the layer's weights (packed16_part) when part of its input was already accumulated into `addend`."""
     a = srcs[0]
+    pc = packed16(conv) if pc is None else pc
     stride = conv.stride[0]
     Ho, Wo = ((a.H - 1) // 2 + 1, (a.W - 1) // 2 + 1) if stride == 2 else (a.H, a.W)
     tc = 0
     if "t2" in _X and conv.kernel_size[0] == 3 and stride == 1 and a.H * a.W >= 10000:
         tc = 101812                      # A/B: two-stage 8-row tiles on every 1/4-scale 3x3 layer
     if want32:
-        return s16.conv2d(packed16(conv), srcs, act=act, addend=addend, post_scale=post_scale, want32=True, stride=stride, tile_cfg=tc,
+        return s16.conv2d(pc, srcs, act=act, addend=addend, post_scale=post_scale, want32=True, stride=stride, tile_cfg=tc,
                           addend16=addend16)[1]
     if out is None:
         out = pool.get((id(conv), tag), a.B, conv.out_channels, Ho, Wo, a.device)
-    return s16.conv2d(packed16(conv), srcs, act=act, addend=addend, post_scale=post_scale, out16=out, stride=stride, tile_cfg=tc,
+    return s16.conv2d(pc, srcs, act=act, addend=addend, post_scale=post_scale, out16=out, stride=stride, tile_cfg=tc,
                       addend16=addend16)[0]
 
 
@@ -438,12 +456,29 @@ class DispGradPredictor(nn.Module):
             cands = ops.grad_candidates(disp)                    # [N,32,H,W] (update.py:202-204)
         pool = pool_of(self)
         c16 = [to16(pool, c, (id(self), "clist_in", i)) for i, c in enumerate(clist)]
-        grad, ctx = self.run(pool, g5, cands, c16)
+        grad, ctx = self.run(pool, g5, cands, self.prepare(pool, c16))
         return grad, ctx.float()
 
-    def run(self, pool, g5: torch.Tensor, cands: torch.Tensor, clist):
-        """g5 = 5 * gradient [N,2,H,W] fp32, cands [N,32,H,W] fp32, clist: 3 S16 context tensors (64 ch at 1/4, 1/8, 1/16)
-        -> (gradient fp32 [N,2,H,W], context S16 [N,64,H,W])."""
+    def prepare(self, pool, clist):
+        """Once per frame.  conv_4_4 / conv_8_8 / conv_16_16 read cat(features, clist[i]) (update.py:205-209) and `clist` does
+        not change over the iterations, so its share of each convolution (40 % / 40 % / 33 % of the input channels) is
+        computed here — bias included — and enters the per-iteration launch as the epilogue's fp32 addend."""
+        pre = []
+        for i, conv in enumerate((self.conv_4_4[0], self.conv_8_8[0], self.conv_16_16[0])):
+            c = clist[i]
+            lo = conv.in_channels - c.C
+            out = pool.get32((id(conv), "ctx_share"), (c.B, conv.out_channels, c.H, c.W), c.device)
+            s16.conv2d(packed16_part(conv, ((lo, conv.in_channels),)), [c], out32=out)
+            pre.append(out)
+        return pre
+
+    def run(self, pool, g5: torch.Tensor, cands: torch.Tensor, pre):
+        """g5 = 5 * gradient [N,2,H,W] fp32, cands [N,32,H,W] fp32, pre: `prepare(pool, clist)` of the 3 S16 context tensors
+        (64 ch at 1/4, 1/8, 1/16) -> (gradient fp32 [N,2,H,W], context S16 [N,64,H,W])."""
+        def feat(conv, srcs, share):
+            n = sum(t.C for t in srcs)
+            return conv16(pool, conv, srcs, act="relu", addend=share, pc=packed16_part(conv, ((0, n),), with_bias=False))
+
         def stem_g():
             return conv16(pool, self.conv_grad_stem[2], [conv32to16(pool, self.conv_grad_stem[0], g5, act="relu")])
 
@@ -451,11 +486,11 @@ class DispGradPredictor(nn.Module):
             return conv16(pool, self.conv_grad_candidate_stem[2], [conv32to16(pool, self.conv_grad_candidate_stem[0], cands, act="relu")])
 
         x4_grad, x4_cand = fork_join([stem_g, stem_c], site="stems")
-        x4 = conv16(pool, self.conv_4_4[0], [x4_grad, x4_cand, clist[0]], act="relu")
+        x4 = feat(self.conv_4_4[0], [x4_grad, x4_cand], pre[0])
         x8 = conv16(pool, self.conv_4_8[0], [x4], act="relu")                    # 3x3 stride 2
-        x8 = conv16(pool, self.conv_8_8[0], [x8, clist[1]], act="relu")
+        x8 = feat(self.conv_8_8[0], [x8], pre[1])
         x16 = conv16(pool, self.conv_8_16[0], [x8], act="relu")                  # 3x3 stride 2
-        x16 = conv16(pool, self.conv_16_16[0], [x16, clist[2]], act="relu")
+        x16 = feat(self.conv_16_16[0], [x16], pre[2])
         x8_up = up_block16(pool, self.conv_16_8, x16, x8)
         x4_up = up_block16(pool, self.conv_8_4, x8_up, x4)
 

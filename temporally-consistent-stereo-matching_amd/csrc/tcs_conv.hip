@@ -206,15 +206,33 @@ __global__ __launch_bounds__(256) void k_conv_cin1(ConvArgs a) {
 // reference's CPU convolution up to summation order): 64 x 4 pixel tile per block, the tile (+3 halo) of every input channel and
 // the block's 49*CIN x 16 weights live in LDS, the filter rows run as a rolled loop so that nothing spills (fully unrolled, the
 // weight reads were hoisted and spilled to scratch).  16 output channels per blockIdx.z.
+// 8 output channels co_lo .. co_lo+7 (one S16 unit) of one pixel -> fp32 NCHW and/or S16
+__device__ __forceinline__ void cin1_store8(const ConvArgs& a, int b, int co_lo, int y, int x, int p, int HW, const float* acc) {
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int co = min(co_lo + c, a.Cout - 1);
+        float t = acc[c] + (a.bias ? a.bias[co] : 0.f);
+        if (a.add1) t += a.add1[((size_t)b * a.Cout + co) * HW + p];
+        v[c] = co_lo + c < a.Cout ? apply_act(t, a.act) * a.post_scale : 0.f;
+    }
+    if (a.out) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (co_lo + c < a.Cout) a.out[((size_t)b * a.out_ctot + a.out_coff + co_lo + c) * HW + p] = v[c];
+    }
+    if (a.out16 && co_lo < a.Cout)
+        s16_store8(a.out16 + s16_unit(b, a.out16_groups, a.out16_goff + (co_lo >> 3), 0, a.H + 2, a.W + 2, y, x), (size_t)(a.H + 2) * (a.W + 2) * 8, v);
+}
+
 template <int CIN>
 __global__ __launch_bounds__(256) void k_conv7x7(ConvArgs a) {
-    constexpr int KS = 7, HALO = 3, TW = 64, TH = 4, IW = TW + 2 * HALO, IH = TH + 2 * HALO;
+    constexpr int KS = 7, HALO = 3, TW = 64, TH = 4, IW = TW + 2 * HALO, IH = TH + 2 * HALO, NC = 8;
     __shared__ float s_in[CIN * IH * IW];
-    __shared__ __attribute__((aligned(16))) float s_w[CIN * KS * KS * 16];
     const int b = blockIdx.y, H = a.H, W = a.W, HW = H * W;
     const int ntx = (W + TW - 1) / TW;
     const int tx0 = (blockIdx.x % ntx) * TW, ty0 = (blockIdx.x / ntx) * TH;
-    const int co_lo = blockIdx.z * 16;
+    const int co_lo = blockIdx.z * NC;
     const float* s = a.src[0] + (size_t)b * CIN * HW;
     for (int i = threadIdx.x; i < CIN * IH * IW; i += 256) {
         const int ci = i / (IH * IW), q = i - ci * (IH * IW);
@@ -224,29 +242,36 @@ __global__ __launch_bounds__(256) void k_conv7x7(ConvArgs a) {
         const float v = s[(size_t)ci * HW + min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)];
         s_in[i] = ok ? v : 0.f;
     }
-    for (int i = threadIdx.x; i < CIN * KS * KS * 16; i += 256) s_w[i] = a.w[(size_t)(i >> 4) * a.CoutPad + co_lo + (i & 15)];
     __syncthreads();
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
-    float acc[16];
+    float acc[NC];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+    for (int c = 0; c < NC; ++c) acc[c] = 0.f;
+    // Weights: the block's NC output channels of one tap are NC contiguous floats of the packed weights at a block-uniform
+    // address, so a filter row is 7 scalar loads (constant cache, 56 SGPRs) issued together.  They must NOT go through LDS:
+    // wave-uniform `ds_read_b128` reads of an LDS copy returned wrong values for lanes 48-63 whenever the workgroup shared its
+    // CU with another kernel's workgroups (tools/race_probe.py; tests/test_gpu_parity.py::test_stem7x7_beside_concurrent_kernels),
+    // although the kernel was correct when it ran alone.
+    const float* wb = a.w + co_lo;
 #pragma unroll 1
     for (int ct = 0; ct < CIN * KS; ++ct) {                  // (input channel, filter row)
         const int ci = ct / KS, ty = ct - ci * KS;
+        float w[KS][NC];
+#pragma unroll
+        for (int tx = 0; tx < KS; ++tx)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) w[tx][c] = wb[(size_t)(ct * KS + tx) * a.CoutPad + c];
+        const float* in_row = s_in + (ci * IH + ly + ty) * IW + lx;
 #pragma unroll
         for (int tx = 0; tx < KS; ++tx) {
-            const float v = s_in[(ci * IH + ly + ty) * IW + lx + tx];
+            const float v = in_row[tx];
 #pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) {
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(&s_w[((ci * KS + ty) * KS + tx) * 16 + c4 * 4]);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c4 * 4 + c] = fmaf(w4[c], v, acc[c4 * 4 + c]);
-            }
+            for (int c = 0; c < NC; ++c) acc[c] = fmaf(w[tx][c], v, acc[c]);
         }
     }
     const int x = tx0 + lx, y = ty0 + ly;
     if (x >= W || y >= H) return;
-    cin1_store16(a, b, co_lo, y, x, y * W + x, HW, acc);
+    cin1_store8(a, b, co_lo, y, x, y * W + x, HW, acc);
 }
 
 __global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ w, int Cout, int Cin, int taps, int CinPad, int CoutPad,
@@ -368,7 +393,7 @@ int tcs_conv2d(const tcs_conv_desc* d, tcs_stream_t stream) {
             if (d->ksize == 1) hipLaunchKernelGGL(k_conv_cin1<1>, grid, dim3(256), 0, s, a);
             else if (d->ksize == 3) hipLaunchKernelGGL(k_conv_cin1<3>, grid, dim3(256), 0, s, a);
             else if (d->ksize == 7) {
-                const dim3 g7(tcs_cdiv(d->W, 64) * tcs_cdiv(d->H, 4), d->B, tcs_cdiv(d->Cout, 16));
+                const dim3 g7(tcs_cdiv(d->W, 64) * tcs_cdiv(d->H, 4), d->B, tcs_cdiv(d->Cout, 8));
                 hipLaunchKernelGGL(k_conv7x7<1>, g7, dim3(256), 0, s, a);
             }
             else return TCS_EUNSUPPORTED;
@@ -377,7 +402,7 @@ int tcs_conv2d(const tcs_conv_desc* d, tcs_stream_t stream) {
         if (d->ksize == 3) return launch_by_tile<3, TCS_EPI_LINEAR>(a, nt, s);
         if (d->ksize == 1) return launch_by_tile<1, TCS_EPI_LINEAR>(a, nt, s);
         if (d->ksize == 7 && d->Cin == 3 && d->n_src == 1 && d->act != TCS_ACT_RELU_ADD_RELU) {   // RGB stem
-            const dim3 g7(tcs_cdiv(d->W, 64) * tcs_cdiv(d->H, 4), d->B, tcs_cdiv(d->Cout, 16));
+            const dim3 g7(tcs_cdiv(d->W, 64) * tcs_cdiv(d->H, 4), d->B, tcs_cdiv(d->Cout, 8));
             hipLaunchKernelGGL(k_conv7x7<3>, g7, dim3(256), 0, s, a);
             return tcs_launch_status();
         }

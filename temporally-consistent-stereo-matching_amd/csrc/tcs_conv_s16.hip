@@ -45,6 +45,8 @@ struct S16Args {
     float post_scale, w_unscale;
     const float* add1;                  // fp32 NCHW addends ([B][Cout or hidden][H][W])
     const float* add2;
+    int add_ctot;                       // channels per batch element of the addend tensors (>= Cout / hidden): lets add1 / add2
+                                        // be channel slices of one wider tensor (the partial sums of a K-split layer)
     const _Float16* add16;              // LINEAR: S16 addend (residual skip), add16_groups groups
     int add16_groups;
     const _Float16* h;                  // GRU: hidden state, S16 [B][h_groups][2][H+2][W+2][8]
@@ -91,7 +93,7 @@ __device__ __forceinline__ void s16_epilogue_tile(const S16Args& a, int b, int c
         if (a.add1) {
             float t[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) t[r] = a.add1[((size_t)b * a.Cout + cc[r]) * HW + pix];
+            for (int r = 0; r < 16; ++r) t[r] = a.add1[((size_t)b * a.add_ctot + cc[r]) * HW + pix];
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = (late ? fmaxf(v[r], 0.f) : v[r]) + t[r];
         }
@@ -155,8 +157,9 @@ __device__ __forceinline__ void s16_epilogue_tile(const S16Args& a, int b, int c
         for (int r = 0; r < 16; ++r) o32[r] = ((size_t)b * a.hidden + chb + (r & 3) + 8 * (r >> 2)) * HW + pix;
         const float* addp = (EPI == TCS_EPI_GRU_ZR && is_r) ? a.add2 : a.add1;
         if (addp) {
+            const size_t shift = (size_t)b * (a.add_ctot - a.hidden) * HW;         // addend batch stride may exceed `hidden`
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ad[r] = addp[o32[r]];
+            for (int r = 0; r < 16; ++r) ad[r] = addp[o32[r] + shift];
         }
         const bool need_h = (EPI == TCS_EPI_GRU_Q) || is_r;
         if (need_h) {
@@ -657,6 +660,11 @@ int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
     }
     if (a.nct32 % ((cfg / 1000) % 10) != 0) return TCS_EUNSUPPORTED;          // the cout tile must divide the packed tiles
 
+    {   // addend channel stride: defaults to the epilogue's own channel count
+        const int own = d->epilogue == TCS_EPI_GRU_ZR ? d->Cout / 2 : d->Cout;
+        if (d->addend_ctot != 0 && d->addend_ctot < own) return TCS_EINVAL;
+        a.add_ctot = d->addend_ctot ? d->addend_ctot : own;
+    }
     switch (d->epilogue) {
         case TCS_EPI_LINEAR:
             if (stride == 2 && d->ksize == 1) return launch_s16_cfg<1, 2, TCS_EPI_LINEAR>(a, cfg, s);

@@ -51,7 +51,7 @@ class ConvS16Desc(C.Structure):
         ("blend_keep_z", c_int),
         ("out16", c_fp), ("out16_groups", c_int), ("out16_group_offset", c_int),
         ("out32", c_fp), ("out_ctot", c_int), ("out_coff", c_int),
-        ("tile_cfg", c_int),
+        ("tile_cfg", c_int), ("addend_ctot", c_int),
     ]
 
 

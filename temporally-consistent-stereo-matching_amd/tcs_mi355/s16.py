@@ -137,15 +137,31 @@ def _desc(pc: PackedConv, srcs: Sequence[S16], stride: int = 1) -> nv.ConvS16Des
     return d
 
 
+def _slice_ptr(t: Optional[torch.Tensor], ctot: int, c: int, grid, name: str):
+    """Device pointer of an fp32 addend: a contiguous [B,c,H,W] tensor (ctot == 0), or a channel slice `base[:, c0:c0+c]` of a
+    contiguous [B,ctot,H,W] tensor — element (b, ch) then lives at ptr + (b*ctot + ch)*H*W, which is what the kernels index."""
+    if t is None:
+        return None
+    B, H, W = grid
+    if not ctot:
+        return nv.ptr(t, name)
+    if t.dtype != torch.float32 or tuple(t.shape) != (B, c, H, W) or t.stride() != (ctot * H * W, H * W, W, 1):
+        raise ValueError(f"{name}: expected a channel slice of a contiguous fp32 [B,{ctot},H,W] tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: tcs_mi355 kernels need a HIP device tensor")
+    return t.data_ptr()
+
+
 def _out_grid(s: S16, stride: int):
     return ((s.H - 1) // 2 + 1, (s.W - 1) // 2 + 1) if stride == 2 else (s.H, s.W)
 
 
 def conv2d(pc: PackedConv, srcs: Sequence[S16], act: str = "none", addend: Optional[torch.Tensor] = None, post_scale: float = 1.0,
            out16: Optional[S16] = None, out16_group_offset: int = 0, out32: Optional[torch.Tensor] = None, out_coff: int = 0,
-           stride: int = 1, want32: bool = False, tile_cfg: int = 0, addend16: Optional[S16] = None):
+           stride: int = 1, want32: bool = False, tile_cfg: int = 0, addend16: Optional[S16] = None, addend_ctot: int = 0):
     """act(conv(cat(srcs)) + bias + addend) * post_scale -> S16 (`out16`, allocated when neither output is given)
-    and/or fp32 NCHW (`out32`, or allocated when want32).  Returns (out16, out32)."""
+    and/or fp32 NCHW (`out32`, or allocated when want32).  Returns (out16, out32).  `addend_ctot` > Cout: `addend` is a
+    channel slice of a [B, addend_ctot, Ho, Wo] tensor (pass the sliced view)."""
     d = _desc(pc, srcs, stride)
     Ho, Wo = _out_grid(srcs[0], stride)
     if out32 is None and want32:
@@ -156,10 +172,10 @@ def conv2d(pc: PackedConv, srcs: Sequence[S16], act: str = "none", addend: Optio
         raise ValueError("conv2d: bad `out16` grid")
     if out32 is not None and (out32.shape[0] != d.B or tuple(out32.shape[2:]) != (Ho, Wo)):
         raise ValueError("conv2d: bad `out32` shape")
-    if addend is not None and tuple(addend.shape) != (d.B, pc.cout, Ho, Wo):
+    if addend is not None and not addend_ctot and tuple(addend.shape) != (d.B, pc.cout, Ho, Wo):
         raise ValueError("conv2d: bad addend shape")
     d.epilogue, d.act, d.post_scale = EPI_LINEAR, ACT[act], float(post_scale)
-    d.addend = nv.ptr(addend, "addend")
+    d.addend, d.addend_ctot = _slice_ptr(addend, addend_ctot, pc.cout, (d.B, Ho, Wo), "addend"), int(addend_ctot)
     if addend16 is not None:
         if (addend16.B, addend16.H, addend16.W) != (d.B, Ho, Wo):
             raise ValueError("conv2d: bad addend16 grid")
@@ -189,8 +205,9 @@ def deconv4x4s2(pc: PackedConv, srcs: Sequence[S16], out16: Optional[S16] = None
 
 
 def gru_gates(pc_zr: PackedConv, srcs: Sequence[S16], h: S16, cz=None, cr=None, z_out: Optional[torch.Tensor] = None,
-              rh_out: Optional[S16] = None, tile_cfg: int = 0):
-    """z = sigmoid(conv_zr[:hid] + cz) (fp32), rh = sigmoid(conv_zr[hid:] + cr) * h (S16)   (update.py:81-83, 30-33)."""
+              rh_out: Optional[S16] = None, tile_cfg: int = 0, addend_ctot: int = 0):
+    """z = sigmoid(conv_zr[:hid] + cz) (fp32), rh = sigmoid(conv_zr[hid:] + cr) * h (S16)   (update.py:81-83, 30-33).
+    `addend_ctot`: cz / cr are channel slices (views) of a [B, addend_ctot, H, W] tensor of partial sums."""
     d = _desc(pc_zr, srcs)
     hid = pc_zr.cout // 2
     if (h.B, h.H, h.W) != (d.B, d.H, d.W) or h.C != hid:
@@ -198,7 +215,9 @@ def gru_gates(pc_zr: PackedConv, srcs: Sequence[S16], h: S16, cz=None, cr=None, 
     z_out = torch.empty(d.B, hid, d.H, d.W, dtype=torch.float32, device=h.device) if z_out is None else z_out
     rh_out = zeros(d.B, hid, d.H, d.W, h.device) if rh_out is None else rh_out
     d.epilogue = EPI_GRU_ZR
-    d.addend, d.addend2 = nv.ptr(cz, "cz"), nv.ptr(cr, "cr")
+    d.addend = _slice_ptr(cz, addend_ctot, hid, (d.B, d.H, d.W), "cz")
+    d.addend2 = _slice_ptr(cr, addend_ctot, hid, (d.B, d.H, d.W), "cr")
+    d.addend_ctot = int(addend_ctot)
     d.h, d.h_groups = h.ptr(), h.G
     d.out32, d.out_ctot, d.out_coff = nv.ptr(z_out, "z"), hid, 0
     d.out16, d.out16_groups, d.out16_group_offset = rh_out.ptr(), rh_out.G, 0
@@ -208,7 +227,7 @@ def gru_gates(pc_zr: PackedConv, srcs: Sequence[S16], h: S16, cz=None, cr=None, 
 
 
 def gru_update(pc_q: PackedConv, srcs: Sequence[S16], h: S16, z: torch.Tensor, cq=None, keep_z: bool = False,
-               out: Optional[S16] = None, out32: Optional[torch.Tensor] = None, tile_cfg: int = 0) -> S16:
+               out: Optional[S16] = None, out32: Optional[torch.Tensor] = None, tile_cfg: int = 0, addend_ctot: int = 0) -> S16:
     """q = tanh(conv_q + cq); h' = (1-z)h + zq (keep_z=False, update.py:85) or zh + (1-z)q (update.py:34,66).
     `out` may be `h` itself (in-place state update: each element is read and written by the same lane)."""
     d = _desc(pc_q, srcs)
@@ -216,7 +235,8 @@ def gru_update(pc_q: PackedConv, srcs: Sequence[S16], h: S16, z: torch.Tensor, c
         raise ValueError("gru_update: bad h/z")
     out = zeros(d.B, pc_q.cout, d.H, d.W, h.device) if out is None else out
     d.epilogue = EPI_GRU_Q
-    d.addend, d.z, d.blend_keep_z = nv.ptr(cq, "cq"), nv.ptr(z, "z"), int(keep_z)
+    d.addend, d.addend_ctot = _slice_ptr(cq, addend_ctot, pc_q.cout, (d.B, d.H, d.W), "cq"), int(addend_ctot)
+    d.z, d.blend_keep_z = nv.ptr(z, "z"), int(keep_z)
     d.h, d.h_groups = h.ptr(), h.G
     d.out16, d.out16_groups, d.out16_group_offset = out.ptr(), out.G, 0
     if out32 is not None:

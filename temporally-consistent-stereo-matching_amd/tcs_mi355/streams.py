@@ -40,17 +40,18 @@ class Spawned:
         self.result, self.stream = result, stream
 
 
-def spawn(fn: Callable[[], object], site: str = "") -> Spawned:
+def spawn(fn: Callable[[], object], site: str = "", slot: int = 0) -> Spawned:
     """Enqueue `fn` on a side stream behind everything already on the current stream and return at once; `join` makes the
-    current stream wait for it.  Used for work whose result is needed much later (the next iteration's gru32)."""
+    current stream wait for it.  Used for work whose result is needed much later (the next iteration's gru32).  Spawns that
+    are in flight at the same time take different `slot`s (one stream each)."""
     global _IN_SIDE, _DEPTH
     if not ENABLED or _IN_SIDE > 0 or not torch.cuda.is_available() or ("all" not in SITES and site not in SITES):
         return Spawned(fn(), None)
     cur = torch.cuda.current_stream()
     pool = _POOL.setdefault((cur.device, "spawn"), [])
-    if not pool:
+    while len(pool) <= slot:
         pool.append(torch.cuda.Stream(device=cur.device))
-    st = pool[0]
+    st = pool[slot]
     st.wait_stream(cur)
     _IN_SIDE += 1
     try:

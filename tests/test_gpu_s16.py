@@ -122,6 +122,38 @@ def test_conv2d_s16_residual_block_pieces(dev):
         assert maxdiff(z16.float(), refn) <= 1e-5
 
 
+def test_conv2d_s16_k_split_accumulation(dev):
+    """A layer evaluated as partial convolutions over slices of its input channels (tcs_mi355.h, addend_ctot): the first
+    partial writes bias + conv_a(a) as fp32, the second adds conv_b(b) in place or applies the real epilogue with the sum
+    as addend — for GRU_ZR with cz / cr being channel slices of ONE [B, 2*hidden, H, W] tensor (batch stride 2*hidden)."""
+    from tcs_mi355 import ops, s16
+    gen = torch.Generator().manual_seed(23)
+    B, hid, H, W = 2, 64, 9, 37
+    h, x = torch.tanh(torch.randn(B, hid, H, W, generator=gen)), torch.randn(B, 96, H, W, generator=gen)
+    wzr = torch.randn(2 * hid, hid + 96, 3, 3, generator=gen) * 0.03
+    bzr, ctx = torch.randn(2 * hid, generator=gen) * 0.1, torch.randn(B, 2 * hid, H, W, generator=gen) * 0.3
+    pre = F.conv2d(torch.cat([h, x], 1).double(), wzr.double(), bzr.double(), padding=1) + ctx.double()
+    z_ref, rh_ref = torch.sigmoid(pre[:, :hid]), torch.sigmoid(pre[:, hid:]) * h.double()
+    h16, x16 = s16.to_s16(D(h, dev)), s16.to_s16(D(x, dev))
+    part = torch.empty(B, 2 * hid, H, W, device=dev)
+    # partial 1: the hidden-state share + bias + context -> fp32 sum
+    s16.conv2d(ops.pack_conv(D(wzr[:, :hid].contiguous(), dev), D(bzr, dev), "f16x3"), [h16], addend=D(ctx, dev), out32=part)
+    assert maxdiff(part, F.conv2d(h.double(), wzr[:, :hid].double(), bzr.double(), padding=1) + ctx.double()) <= 2e-5
+    # final: the input share with the gate epilogue, addends = channel slices of the sum
+    pc_x = ops.pack_conv(D(wzr[:, hid:].contiguous(), dev), None, "f16x3")
+    z, rh = s16.gru_gates(pc_x, [x16], h16, part[:, :hid], part[:, hid:], addend_ctot=2 * hid)
+    assert maxdiff(z, z_ref) <= 1e-5 and maxdiff(rh.float(), rh_ref) <= 1e-5
+    # LINEAR: in-place accumulation of a second partial, and a sliced addend
+    acc = part.clone()
+    s16.conv2d(pc_x, [x16], addend=acc, out32=acc)
+    assert maxdiff(acc, pre) <= 2e-5
+    o, _ = s16.conv2d(ops.pack_conv(D(wzr[:hid, hid:].contiguous(), dev), None, "f16x3"), [x16], act="relu", addend=part[:, hid:],
+                      addend_ctot=2 * hid)
+    assert maxdiff(o.float(), torch.relu(F.conv2d(x.double(), wzr[:hid, hid:].double(), padding=1) + part[:, hid:].double().cpu())) <= 2e-5
+    with pytest.raises(ValueError):
+        s16.gru_gates(pc_x, [x16], h16, part[:, :hid].contiguous(), part[:, hid:], addend_ctot=2 * hid)   # not a slice of a wider tensor
+
+
 def test_conv2d_s16_partial_store_keeps_foreign_channel(dev):
     """encoder.conv writes 127 channels into the 128-channel motion buffer whose channel 127 belongs to the blend kernel."""
     from tcs_mi355 import ops, s16

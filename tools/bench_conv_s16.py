@@ -3,7 +3,7 @@
 on-the-fly split) on the refinement loop's layer shapes (GPU box).  For every shape and tile configuration: max abs difference
 to the old kernel's output (both contract the same fp16 halves, so they agree to fp32 summation order) and us per launch from
 a HIP-graph replay of a burst of launches timed with HIP events.
-usage: bench_conv_s16.py [only-substring] ; env CFGS=1413,2413,... restricts the tile configurations."""
+usage: bench_conv_s16.py [only-substring] ; env CFGS=1413,2413,... restricts the tile configurations, BATCH=n sets the batch."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -37,6 +37,7 @@ CFGS3 = [101412, 101812, 101411, 102411, 101811, 102812, 102512]
 CFGS1 = [1422, 101422, 2422, 102422, 202422, 1442, 2442, 102442]
 only = sys.argv[1] if len(sys.argv) > 1 else ""
 forced = [int(c) for c in os.environ.get("CFGS", "").split(",") if c]
+NB = int(os.environ.get("BATCH", "1"))          # BATCH=4: steady-state throughput of a layer (4x the workgroups)
 gen = torch.Generator().manual_seed(0)
 
 
@@ -65,10 +66,10 @@ for name, cins, cout, k, H, W, epi, stride in SHAPES:
     if only and only not in name:
         continue
     cin = sum(cins)
-    xs = [torch.randn(1, c, H, W, generator=gen).to(dev) for c in cins]
+    xs = [torch.randn(NB, c, H, W, generator=gen).to(dev) for c in cins]
     hid = cout // 2 if epi == "zr" else cout
-    h = torch.randn(1, hid, H, W, generator=gen).to(dev)
-    z = torch.rand(1, hid, H, W, generator=gen).to(dev)
+    h = torch.randn(NB, hid, H, W, generator=gen).to(dev)
+    z = torch.rand(NB, hid, H, W, generator=gen).to(dev)
     if epi == "deconv":
         wt = (torch.randn(cin, cout, 4, 4, generator=gen) * 0.02).to(dev)
         pc = ops.pack_deconv4x4s2(wt)
@@ -76,7 +77,7 @@ for name, cins, cout, k, H, W, epi, stride in SHAPES:
         w = (torch.randn(cout, cin, k, k, generator=gen) * 0.02).to(dev)
         b = (torch.randn(cout, generator=gen) * 0.1).to(dev)
         pc = ops.pack_conv(w, b, "f16x3")
-    add = torch.randn(1, hid if epi in ("zr", "q") else cout, (H - 1) // stride + 1, (W - 1) // stride + 1, generator=gen).to(dev)
+    add = torch.randn(NB, hid if epi in ("zr", "q") else cout, (H - 1) // stride + 1, (W - 1) // stride + 1, generator=gen).to(dev)
     xs16 = [s16.to_s16(x) for x in xs]
     h16 = s16.to_s16(h)
 
@@ -107,12 +108,12 @@ for name, cins, cout, k, H, W, epi, stride in SHAPES:
         o16, o32 = s16.conv2d(pc, xs16, act="relu", addend=add, stride=stride, out16=outs.get("o16"), out32=outs.get("o32"), want32=True,
                               tile_cfg=cfg)
         if outs.get("o16") is None:
-            outs.update(o16=s16.zeros(1, cout, o32.shape[2], o32.shape[3], dev), o32=o32)
+            outs.update(o16=s16.zeros(NB, cout, o32.shape[2], o32.shape[3], dev), o32=o32)
         return (o32,)
 
     ref = [t.clone() for t in old()]
     t_old = timed(old)
-    macs = ((H - 1) // stride + 1) * ((W - 1) // stride + 1) * cin * cout * k * k
+    macs = NB * ((H - 1) // stride + 1) * ((W - 1) // stride + 1) * cin * cout * k * k
     line = f"{name:16s} {H}x{W} cin {cin:4d} cout {cout:4d}: old {t_old:7.1f} us {2.0 * macs / t_old / 1e6:6.1f} TF |"
     cfgs = forced or ([0] + (CFGS1 if k == 1 else ([1412] if stride == 2 else CFGS3)))
     for cfg in cfgs:
