@@ -375,13 +375,17 @@ def main():
         torch.cuda.synchronize()
         tdist.barrier()
         t0 = time.perf_counter()
-        for _ in range(a.steps):
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+        for i in range(a.steps):
+            marks[i].record()                      # per-step spread (diagnostic): events only, no host sync inside the region
             runner.step()
             snaps.append(probe.buf.clone())        # stream-ordered 300 KB copy + clear; no host sync
             probe.reset()
+        marks[-1].record()
         torch.cuda.synchronize()
         tdist.barrier()
         elapsed = time.perf_counter() - t0
+        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
     ops.LOOKUP_PROBE = None
     graphs = getattr(model, "_graphs", None)
     if not a.eager and (graphs is None or graphs.fell_back or any(v is None for v in graphs.cache.values())):
@@ -464,6 +468,7 @@ def main():
         line = {
             "metric": f"stereo-pairs/sec at {WIDTH}x{HEIGHT} D=192, 32 GRU iters", "value": round(value, 4), "unit": "stereo-pairs/s",
             "n_gpus": max(world, 1), "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
+            "step_ms_min_median_max": [round(per_step[0], 3), round(per_step[len(per_step) // 2], 3), round(per_step[-1], 3)],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "contraction": CONTRACTION,
             "config": {"workload": ("BASELINE configs[1]: 640x480" if (HEIGHT, WIDTH) == (480, 640) else f"{WIDTH}x{HEIGHT}")

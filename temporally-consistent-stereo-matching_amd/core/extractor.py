@@ -203,19 +203,28 @@ class MultiBasicEncoder(nn.Module):
         self.dropout = nn.Dropout2d(p=dropout) if dropout > 0 else None
         _init(self, "fan_out")
 
-    def _forward16(self, x, dual_inp, num_layers):
-        """`none`-norm context network end to end on pre-split tensors: the stem writes S16, every residual block stays S16, only
-        the heads' final convolutions produce fp32.  With `dual_inp` the trunk (an S16 tensor) is returned last, for the matching-feature head."""
+    def can16(self, x) -> bool:
+        """The all-S16 path: HIP device tensor, `none` norm, stride-1 stem."""
+        from core.update import _X
+        return bool(x.is_cuda and _hip_trunk() and self.norm_fn == "none" and self.conv1.stride == (1, 1) and "noext16" not in _X)
+
+    def trunk16(self, x) -> "s16.S16":
+        """Stem + layer1..3 on pre-split tensors (`none` norm): the stem writes S16 and every residual block stays S16."""
         from core.update import conv32to16, pool_of
         pool = pool_of(self)
         x = conv32to16(pool, self.conv1, x.float().contiguous(), act="relu")                       # 7x7 stem, S16 epilogue
         for layer in (self.layer1, self.layer2, self.layer3):
             for blk in layer:
                 x = blk.run16(pool, x)
-        tail = ()
+        return x
+
+    def heads16(self, x: "s16.S16", dual_inp, num_layers):
+        """The per-scale heads on the S16 trunk; only their final convolutions produce fp32.  With `dual_inp` the trunk holds
+        left and right images (batch-major) and the heads read the left half."""
+        from core.update import pool_of
+        pool = pool_of(self)
         if dual_inp:
-            tail = (x,)
-            x = s16.S16(x.data[: x.B // 2], x.C)                                                    # left images only (batch-major layout)
+            x = s16.S16(x.data[: x.B // 2], x.C)
         scales = [[hip_head16(pool, f, x) for f in self.outputs08]]
         if num_layers >= 2:
             y = x
@@ -227,12 +236,12 @@ class MultiBasicEncoder(nn.Module):
             for blk in self.layer5:
                 z = blk.run16(pool, z)
             scales.append([hip_head16(pool, f, z) for f in self.outputs32])
-        return (*scales, *tail)
+        return scales
 
     def forward(self, x, dual_inp=False, num_layers=3):
-        from core.update import _X
-        if x.is_cuda and _hip_trunk() and self.norm_fn == "none" and self.conv1.stride == (1, 1) and "noext16" not in _X:
-            return self._forward16(x, dual_inp, num_layers)
+        if self.can16(x):
+            trunk = self.trunk16(x)
+            return (*self.heads16(trunk, dual_inp, num_layers), *((trunk,) if dual_inp else ()))
         x = hip_stem(self, x)
         x = self.layer3(self.layer2(self.layer1(x)))
         tail = ()

@@ -133,27 +133,54 @@ class TCStereo(nn.Module):
         a = self.args
         image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
         image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
-        cnet_list, fmap1, fmap2 = self._extract(image1, image2)
-
         first = temporal is None
-        corr_fn = CorrBlock1D(fmap1, fmap2, radius=a.corr_radius, num_levels=a.corr_levels, thres=a.init_thres,
-                              want_argmax=first)
-        if first:
-            sparse_disp, cost, sparse_mask = corr_fn.argmax_disp()
-            last_net_list = None
-        else:
+        if not first:
             K, T, previous_T, baseline, last_disp, last_net_list, last_fmap1 = temporal
+        else:
+            last_net_list = None
+
+        def matching(fmap1, fmap2):
+            """Correlation pyramid + the sparse disparity prior: arg-max of the cost volume (first frame) or the pose warp of
+            the previous frame's disparity and features (tc_stereo.py:121-149)."""
+            corr_fn = CorrBlock1D(fmap1, fmap2, radius=a.corr_radius, num_levels=a.corr_levels, thres=a.init_thres, want_argmax=first)
+            if first:
+                return (corr_fn, *corr_fn.argmax_disp(), None)
             # K_scale, its inverse, T @ inv(previous_T), previous_T @ inv(T): one tiny kernel, no host sync
             K_scale, K_scale_inv, relative_T, back_T = ops.pose_prepare(K, T, previous_T, self.scale_rate)
             # warp + normalise + cosine cost in one launch sequence; the warped feature map is never materialised
             sparse_disp, _, sparse_mask, cost = ops.warp_forward(
                 (-last_disp).float().contiguous(), last_fmap1.float().contiguous(), relative_T, K_scale,
                 K_scale_inv, baseline, cur_fmap=fmap1, want_fmap=False)
+            return corr_fn, sparse_disp, cost, sparse_mask, (K_scale, K_scale_inv, back_T)
 
-        inp_list = [torch.relu(x[1]) for x in cnet_list]
-        grad_list = [hip_conv(conv, [i]) for i, conv in zip(inp_list, self.context_zqr_convs_grad)]
-        inp_list = [[c.contiguous() for c in hip_conv(conv, [i]).chunk(3, 1)] for i, conv in zip(inp_list, self.context_zqr_convs)]
-        net_list = [x[0] for x in cnet_list]
+        def context(cnet_list):
+            """Per-scale context terms of the GRUs and of the gradient predictor (tc_stereo.py:151-156): once per frame."""
+            inp = [torch.relu(x[1]) for x in cnet_list]
+            grads = [hip_conv(conv, [i]) for i, conv in zip(inp, self.context_zqr_convs_grad)]
+            zqr = [[c.contiguous() for c in hip_conv(conv, [i]).chunk(3, 1)] for i, conv in zip(inp, self.context_zqr_convs)]
+            return zqr, grads, [x[0] for x in cnet_list]
+
+        both = torch.cat((image1, image2), 0)
+        if a.shared_backbone and self.cnet.can16(both):
+            # the matching side (feature head -> correlation build -> prior) and the context side (per-scale heads -> context
+            # convolutions) both start from the shared trunk and meet at the disparity completion: parallel graph branches
+            from tcs_mi355.streams import fork_join
+            trunk = self.cnet.trunk16(both)
+
+            def matching_side():
+                fm = hip_head(self.conv2, trunk)
+                f1, f2 = (t.float().contiguous() for t in fm.split(fm.shape[0] // 2, 0))
+                return f1, f2, matching(f1, f2)
+
+            (fmap1, fmap2, match), (inp_list, grad_list, net_list) = fork_join(
+                [matching_side, lambda: context(self.cnet.heads16(trunk, True, a.n_gru_layers))], site="frame")
+        else:
+            cnet_list, fmap1, fmap2 = self._extract(image1, image2)
+            match = matching(fmap1, fmap2)
+            inp_list, grad_list, net_list = context(cnet_list)
+        corr_fn, sparse_disp, cost, sparse_mask, pose = match
+        if pose is not None:
+            K_scale, K_scale_inv, back_T = pose
 
         disp_init, _, _, net_list = self.disp_completor(sparse_disp, cost, sparse_mask, net_list)
         disp_init = disp_init.float().contiguous()

@@ -11,18 +11,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ------------------------------------------------------------------------------------------------
 // 1. inverse L2 norms over channels (F.normalize, corr.py:58-59; eps 1e-12)
 // ------------------------------------------------------------------------------------------------
+// One block = 64 consecutive pixels x 4 channel quarters (a wave each); the quarters' sums are added in a fixed order.
 __global__ __launch_bounds__(256) void k_inv_norm(const float* __restrict__ f1, const float* __restrict__ f2,
                                                   int C, int HW, float* __restrict__ rn) {
-    const int p = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float s_part[4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int p_raw = blockIdx.x * 64 + lane;
     const int b = blockIdx.y, m = blockIdx.z;
-    if (p >= HW) return;
+    const int p = min(p_raw, HW - 1);
     const float* f = (m == 0 ? f1 : f2) + (size_t)b * C * HW + p;
+    const int cq = (C + 3) / 4, c_hi = min(C, (q + 1) * cq);
     float s = 0.f;
-    for (int c = 0; c < C; ++c) {
+    for (int c = q * cq; c < c_hi; ++c) {
         const float v = f[(size_t)c * HW];
         s = fmaf(v, v, s);
     }
-    rn[((size_t)m * gridDim.y + b) * HW + p] = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+    s_part[q][lane] = s;
+    __syncthreads();
+    if (q == 0 && p_raw < HW) {
+        const float t = ((s_part[0][lane] + s_part[1][lane]) + s_part[2][lane]) + s_part[3][lane];
+        rn[((size_t)m * gridDim.y + b) * HW + p] = 1.0f / fmaxf(sqrtf(t), 1e-12f);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -334,7 +343,7 @@ int tcs_corr_build(const float* fmap1, const float* fmap2, int B, int C, int H, 
     float* vol = reinterpret_cast<float*>(workspace);
     float* rn = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + align256((size_t)B * H * W * W * sizeof(float)));
     const int HW = H * W;
-    hipLaunchKernelGGL(k_inv_norm, dim3(tcs_cdiv(HW, 256), B, 2), dim3(256), 0, s, fmap1, fmap2, C, HW, rn);
+    hipLaunchKernelGGL(k_inv_norm, dim3(tcs_cdiv(HW, 64), B, 2), dim3(256), 0, s, fmap1, fmap2, C, HW, rn);
     hipLaunchKernelGGL(k_corr_gemm, dim3(tcs_cdiv(W, 64), tcs_cdiv(W, 64), B * H), dim3(256), 0, s,
                        fmap1, fmap2, rn, B, C, H, W, vol);
     FinalizeArgs fa;

@@ -146,22 +146,29 @@ __global__ __launch_bounds__(256) void k_zero_fill(float4* __restrict__ p, size_
 }
 
 // normalise (softsplat.py:257-270, 'clipeps'), split, and the temporal cost (tc_stereo.py:139-140)
+// One block = 64 consecutive pixels x 4 channel quarters (one wave each: coalesced rows of 64 floats per channel); the
+// three sums of the cosine are combined across the quarters through LDS in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void k_warp_finish(const float* __restrict__ acc, const float* __restrict__ cur_fmap,
                                                      int C, int HW, float* __restrict__ out_disp, float* __restrict__ out_fmap,
                                                      float* __restrict__ out_mask, float* __restrict__ out_cost) {
-    const int b = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= HW) return;
+    __shared__ float s_part[3][4][64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int p_raw = blockIdx.x * 64 + lane;
+    const bool active = p_raw < HW;
+    const int p = active ? p_raw : HW - 1;
     const float* a = acc + (size_t)b * (C + 2) * HW + p;
     const float norm = a[(size_t)(C + 1) * HW];
     const float mask = (norm != 0.f) ? 1.f : 0.f;
     const float den = fmaxf(norm, 1e-7f);
-    out_disp[(size_t)b * HW + p] = a[(size_t)C * HW] / den;
-    out_mask[(size_t)b * HW + p] = mask;
+    if (q == 0 && active) {
+        out_disp[(size_t)b * HW + p] = a[(size_t)C * HW] / den;
+        out_mask[(size_t)b * HW + p] = mask;
+    }
+    const int cq = (C + 3) / 4, c_lo = q * cq, c_hi = min(C, c_lo + cq);
     float dot = 0.f, n1 = 0.f, nw = 0.f;
-    for (int c = 0; c < C; ++c) {
+    for (int c = c_lo; c < c_hi; ++c) {
         const float fw = a[(size_t)c * HW] / den;
-        if (out_fmap) out_fmap[((size_t)b * C + c) * HW + p] = fw;
+        if (out_fmap && active) out_fmap[((size_t)b * C + c) * HW + p] = fw;
         if (out_cost) {
             const float f1 = cur_fmap[((size_t)b * C + c) * HW + p];
             dot = fmaf(f1, fw, dot);
@@ -169,7 +176,15 @@ __global__ __launch_bounds__(256) void k_warp_finish(const float* __restrict__ a
             nw = fmaf(fw, fw, nw);
         }
     }
-    if (out_cost) out_cost[(size_t)b * HW + p] = dot / (fmaxf(sqrtf(n1), 1e-12f) * fmaxf(sqrtf(nw), 1e-12f)) * mask;
+    if (!out_cost) return;
+    s_part[0][q][lane] = dot; s_part[1][q][lane] = n1; s_part[2][q][lane] = nw;
+    __syncthreads();
+    if (q == 0 && active) {
+        float t[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t[k] = ((s_part[k][0][lane] + s_part[k][1][lane]) + s_part[k][2][lane]) + s_part[k][3][lane];
+        out_cost[(size_t)b * HW + p] = t[0] / (fmaxf(sqrtf(t[1]), 1e-12f) * fmaxf(sqrtf(t[2]), 1e-12f)) * mask;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -371,7 +386,7 @@ int tcs_warp_forward(const float* prev_disp, const float* prev_fmap, const float
     const int cpg = 16, groups = tcs_cdiv(C + 2, cpg);
     hipLaunchKernelGGL(k_splat<1>, dim3(nb, B, groups), dim3(256), 0, s, prev_fmap, w.flow, w.cur_disp, w.valid, w.mean,
                        C, H, W, cpg, w.acc);
-    hipLaunchKernelGGL(k_warp_finish, dim3(nb, B), dim3(256), 0, s, w.acc, cur_fmap, C, H * W, out_disp, out_fmap,
+    hipLaunchKernelGGL(k_warp_finish, dim3(tcs_cdiv((long long)H * W, 64), B), dim3(256), 0, s, w.acc, cur_fmap, C, H * W, out_disp, out_fmap,
                        out_mask, out_cost);
     return tcs_launch_status();
 }
