@@ -398,7 +398,7 @@ __device__ __forceinline__ float hu_tanh(float v) {
     return 1.0f - 2.0f * hu_rcp(e + 1.0f);
 }
 
-#define HU_WAVES 2
+#define HU_WAVES 4
 #define HU_NBIAS (64 + 64 + 64 + 256 + 128)           // w1, b1, b2, bzr, bq
 __global__ __launch_bounds__(64 * HU_WAVES) void k_hidden_update_s16(HuArgs a) {
     extern __shared__ __attribute__((aligned(16))) float hu_lds[];            // [HU_NBIAS] biases, then z gates: [wave][64 regs][64 lanes]

@@ -6,17 +6,9 @@ replayed.  Inputs are copied into the graph's static buffers, outputs are cloned
 keep ordinary tensor semantics (the temporal state they pass back next frame is theirs).  The
 library kernels are capture-safe by construction (no allocation, no sync, stream-ordered memset
 only — include/tcs_mi355.h); the PyTorch-ROCm parts (extractor, U-Nets) are captured by torch.
-
-Capture tournament.  The frame graph has parallel branches (tcs_mi355/streams.py), and on ROCm 7.2 the time of a replay
-depends on the individual capture: instantiations of the SAME launch sequence land in two groups, ~28.5 ms and 31-36 ms per
-640x480 frame, roughly one capture in four in the slow group (tools/capture_variance.py; the runtime's placement of graph
-branches on hardware queues is not under the caller's control).  `_capture` therefore captures `tries` candidates
-(TCS_MI355_GRAPH_TRIES, default 3), times two replays of each on the real inputs — a replay only rewrites the graph's own
-buffers, so repeating a frame is harmless — and keeps the fastest.
 """
 from __future__ import annotations
 
-import os
 import warnings
 from typing import Callable, Dict, Optional
 
@@ -47,11 +39,8 @@ class FrameGraphs:
     so every entry is dropped and re-captured when it changes.  `fell_back` counts the frames that ran eagerly because
     a capture failed; `strict=True` turns such a failure into an error instead (bench.py, tests)."""
 
-    def __init__(self, frame_fn: Callable, warmup: int = 2, epoch_fn: Optional[Callable[[], object]] = None, strict: bool = False,
-                 tries: Optional[int] = None):
+    def __init__(self, frame_fn: Callable, warmup: int = 2, epoch_fn: Optional[Callable[[], object]] = None, strict: bool = False):
         self.frame_fn, self.warmup, self.epoch_fn, self.strict = frame_fn, warmup, epoch_fn, strict
-        self.tries = max(1, int(os.environ.get("TCS_MI355_GRAPH_TRIES", "3")) if tries is None else int(tries))
-        self.candidate_ms = []             # replay time of every candidate of the most recent capture (diagnostics)
         self.cache: Dict[tuple, Optional[_Entry]] = {}
         self.epoch = epoch_fn() if epoch_fn is not None else None
         self.fell_back = 0
@@ -71,28 +60,11 @@ class FrameGraphs:
                     run()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            best, self.candidate_ms = None, []
-            for _ in range(self.tries):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    out = run()
-                if self.tries > 1:
-                    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    g.replay()
-                    t0.record()
-                    g.replay()
-                    g.replay()
-                    t1.record()
-                    torch.cuda.synchronize()
-                    ms = t0.elapsed_time(t1) / 2
-                else:
-                    ms = 0.0
-                self.candidate_ms.append(round(ms, 3))
-                if best is None or ms < best[0]:
-                    best = (ms, g, out)
-                del g, out
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = run()
             self.captures += 1
-            return _Entry(best[1], static_in, best[2])
+            return _Entry(g, static_in, out)
         except Exception as e:  # capture is an optimisation: the eager HIP path computes the same thing
             if self.strict:
                 raise

@@ -7,7 +7,7 @@ run() { TCS_MI355_FORK_SITES=$1 python bench.py --steps 10 --warmup 3 --no-cpu-b
 for r in $(seq 1 $rounds); do
   echo "round $r all: $(run all)"
   for s in "$@"; do
-    sites=$(echo $ALL | tr ',' '\n' | grep -v "^$s\$" | paste -sd, -)
+    sites=$(echo $ALL | tr ',' '\n' | grep -v -x -E "$(echo $s | tr '+' '|')" | paste -sd, -)    # "a+b" removes both
     echo "round $r minus $s: $(run $sites)"
   done
 done

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Is the frame time a property of the process or of the capture?  One process captures the temporal frame graph several
-times (the graph cache is dropped between attempts) and times replays of each capture.  (GPU box.)
+"""Where do slow bench runs come from?  One process captures the temporal frame graph several times (the graph cache is
+dropped between attempts) and replays each capture for 8 frames: mean, per-frame GPU time (events) and per-frame HOST time
+of the enqueue (no sync).  Finding (profiles/r02_step_jitter.txt): every capture replays at the same speed; slow means come
+from bursts of individual slow frames (50-60 ms), i.e. from the box, not from the graph.  (GPU box.)
 usage: capture_variance.py [captures] ; env TCS_MI355_X / TCS_MI355_FORK_SITES select the schedule."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,10 +26,20 @@ with torch.no_grad():
         runner.step(); runner.step(); runner.step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(8):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(9)]
+        host = []
+        for i in range(8):
+            ev[i].record()
+            h0 = time.perf_counter()
             runner.step()
+            host.append(1e3 * (time.perf_counter() - h0))
+        ev[8].record()
         torch.cuda.synchronize()
-        res.append(1e3 * (time.perf_counter() - t0) / 8)
+        steps = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(8))
+        host.sort()
+        res.append((1e3 * (time.perf_counter() - t0) / 8, steps[0], steps[4], steps[-1], host[0], host[4], host[-1]))
         if runner.t > 8:
             runner.t, runner.state = 0, None
-print("ms per frame for each capture:", " ".join(f"{r:.2f}" for r in res))
+for r in res:
+    print(f"capture: mean {r[0]:.2f} ms per frame; GPU per-frame min {r[1]:.2f} median {r[2]:.2f} max {r[3]:.2f}; "
+          f"host enqueue per frame min {r[4]:.2f} median {r[5]:.2f} max {r[6]:.2f}")
