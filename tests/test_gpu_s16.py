@@ -59,6 +59,7 @@ CONV_CASES = [
     dict(B=1, cins=(256,), cout=1, k=3, H=6, W=32),                   # flow head conv2: one output channel
     dict(B=1, cins=(128,), cout=9, k=1, H=11, W=33),                  # w_head[2]
     dict(B=1, cins=(128, 64), cout=96, k=3, H=17, W=35),              # odd grid, 96 outputs (3 tiles)
+    dict(B=1, cins=(128, 64), cout=256, k=1, H=9, W=35),              # a 1x1 gate convolution (Lightfuse-like): 64-channel tiles, 2/4 k-steps per stage
     dict(B=1, cins=(64,), cout=96, k=3, H=16, W=34, stride=2),        # conv_4_8
     dict(B=1, cins=(96,), cout=128, k=3, H=15, W=33, stride=2),       # stride 2 on an odd grid
 ]
@@ -77,10 +78,19 @@ def test_conv2d_s16_vs_torch(dev, cfg):
     pc = ops.pack_conv(D(w, dev), D(b, dev), "f16x3")
     xs16 = [s16.to_s16(D(x, dev)) for x in xs]
     tiles = [0]
+    # every tile configuration the library instantiates (launch_s16_cfg): MT*1000 + ROWS*100 + KSTEPS*10 + NSTAGE, +10000 row split,
+    # +100000*CSPLIT block -> XCD mapping; 64-channel tiles (MT = 2) need an even number of 32-channel tiles
     if cfg["k"] == 3 and stride == 1:
-        tiles += [1412, 1413, 101812, 201412] + ([2412, 102812, 12412] if cfg["cout"] % 64 == 0 else [])
-    elif cfg["k"] == 1:
-        tiles += [1412, 101422] if cin % 32 == 0 else [1412]
+        tiles += [1411, 1412, 1413, 1811, 1512, 101812, 201412]
+        tiles += [2411, 2412, 2413, 2512, 102812, 12412, 12413] if cfg["cout"] % 64 == 0 else []
+    elif cfg["k"] == 1 and stride == 1:
+        ksteps = [(c + 15) // 16 for c in cfg["cins"]]
+        tiles += [1412]
+        for kst in (2, 4):
+            if all(k % kst == 0 for k in ksteps):
+                tiles += [1400 + 10 * kst + 2, 101400 + 10 * kst + 2] + ([1423] if kst == 2 else [])
+                tiles += ([2400 + 10 * kst + 2] + ([2423] if kst == 2 else [])) if cfg["cout"] % 64 == 0 else []
+        tiles += [2412] if cfg["cout"] % 64 == 0 else []
     for tc in tiles:
         o16, o32 = s16.conv2d(pc, xs16, want32=True, stride=stride, tile_cfg=tc)
         assert maxdiff(o32, ref) <= 2e-5, tc
