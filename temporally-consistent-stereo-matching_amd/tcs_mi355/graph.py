@@ -6,11 +6,19 @@ replayed.  Inputs are copied into the graph's static buffers, outputs are cloned
 keep ordinary tensor semantics (the temporal state they pass back next frame is theirs).  The
 library kernels are capture-safe by construction (no allocation, no sync, stream-ordered memset
 only — include/tcs_mi355.h); the PyTorch-ROCm parts (extractor, U-Nets) are captured by torch.
+
+Two instantiations per key, used in turn (`copies`, TCS_MI355_GRAPH_COPIES).  On ROCm 7.2 a graph WITH parallel branches
+(tcs_mi355/streams.py) is not fire-and-forget: launching an executable graph again blocks the host until its previous
+launch has nearly finished (median 19 ms per 28 ms frame; a linear graph returns in 0.7 ms), so the host can never run
+ahead and every scheduling hiccup becomes a GPU bubble.  Alternating between two executables of the same capture lets
+the host enqueue frame t+1 while frame t runs (6.5 ms per launch, tools/capture_variance.py).  Both use the same static
+input buffers and the same persistent pool buffers; stream order keeps their replays sequential on the GPU.
 """
 from __future__ import annotations
 
+import os
 import warnings
-from typing import Callable, Dict, Optional
+from typing import Callable, Dict, List, Optional
 
 import torch
 
@@ -39,9 +47,12 @@ class FrameGraphs:
     so every entry is dropped and re-captured when it changes.  `fell_back` counts the frames that ran eagerly because
     a capture failed; `strict=True` turns such a failure into an error instead (bench.py, tests)."""
 
-    def __init__(self, frame_fn: Callable, warmup: int = 2, epoch_fn: Optional[Callable[[], object]] = None, strict: bool = False):
+    def __init__(self, frame_fn: Callable, warmup: int = 2, epoch_fn: Optional[Callable[[], object]] = None, strict: bool = False,
+                 copies: Optional[int] = None):
         self.frame_fn, self.warmup, self.epoch_fn, self.strict = frame_fn, warmup, epoch_fn, strict
-        self.cache: Dict[tuple, Optional[_Entry]] = {}
+        self.copies = max(1, int(os.environ.get("TCS_MI355_GRAPH_COPIES", "2")) if copies is None else int(copies))
+        self.turn: Dict[tuple, int] = {}
+        self.cache: Dict[tuple, Optional[List[_Entry]]] = {}
         self.epoch = epoch_fn() if epoch_fn is not None else None
         self.fell_back = 0
         self.captures = 0
@@ -60,11 +71,17 @@ class FrameGraphs:
                     run()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = run()
+            entries = []
+            for _ in range(self.copies):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = run()
+                g.replay()          # the first launch of an executable graph uploads it (~30 ms): pay that here, not in a timed frame;
+                                    # a replay only rewrites the graph's own buffers and the pool, so repeating the frame is harmless
+                entries.append(_Entry(g, static_in, out))
+            torch.cuda.synchronize()
             self.captures += 1
-            return _Entry(g, static_in, out)
+            return entries
         except Exception as e:  # capture is an optimisation: the eager HIP path computes the same thing
             if self.strict:
                 raise
@@ -82,10 +99,13 @@ class FrameGraphs:
         key = self._key(image1, iters, flat)
         if key not in self.cache:
             self.cache[key] = self._capture(image1, image2, iters, flat)
-        e = self.cache[key]
-        if e is None:
+        entries = self.cache[key]
+        if entries is None:
             self.fell_back += 1
             return self.frame_fn(image1, image2, iters, temporal)
+        turn = self.turn.get(key, 0)
+        self.turn[key] = (turn + 1) % len(entries)
+        e = entries[turn]
         for dst, src in zip(e.static_in, [image1, image2, *flat]):
             dst.copy_(src)
         e.graph.replay()
