@@ -19,7 +19,7 @@ import torch.nn as nn
 from core.corr import CorrBlock1D
 from core.extractor import BasicEncoder, MultiBasicEncoder, ResidualBlock, hip_head
 from core.update import (BasicMultiUpdateBlock, DispGradPredictor, DispRefine, DisparityCompletor, HiddenstateUpdater,
-                         Lightfuse, hip_conv)
+                         Lightfuse, _X, hip_conv)
 from core.utils.utils import coords_grid
 from tcs_mi355 import ops, s16
 
@@ -227,7 +227,8 @@ class TCStereo(nn.Module):
         for itr in range(iters):
             # Two independent chains open an iteration: [hidden-state update of the previous iteration -> gru32 -> gru16 ->
             # interp] needs only the hidden states; [corr lookup -> motion encoder] needs only coords1 / the flow written by the
-            # previous blend.  They run as parallel branches (streams.py); gru08 joins them.
+            # previous blend.  They run as parallel branches (streams.py); gru08 joins them.  gru32 of the next iteration and the
+            # share of gru16 that reads only net16 / interp(net32) run ahead, beside gru08 / flow head / refinement (update.py).
             def enc_branch():
                 corr = corr_fn(coords1)
                 return corr, ub.encoder.run(pool, flows_x, corr, motion)
@@ -235,6 +236,8 @@ class TCStereo(nn.Module):
             def coarse_branch():
                 if hu_delta is not None:
                     self.hiddenstate_update.run(pool, nets[0], hu_delta)
+                if isinstance(up32_now, tuple):          # gru32 ran ahead together with the early share of gru16
+                    return ub.gru16_late(pool, nets, up32_now[1])
                 if n3 and a.slow_fast_gru:
                     ub.run_coarse(pool, nets, inp_list, iter16=False, iter32=True, want_up16=False)
                 if a.n_gru_layers >= 2 and a.slow_fast_gru:
@@ -246,7 +249,10 @@ class TCStereo(nn.Module):
             (corr, m), up16 = fork_join([enc_branch, coarse_branch], site="iter")
             if plain and trace is None and itr + 1 < iters:
                 # net16 is final for this iteration: gru32 of the NEXT iteration runs beside gru08 / flow head / refinement
-                early32 = spawn(lambda: ub.run_gru32(pool, nets, inp_list), site="gru32")
+                def ahead():
+                    up32 = ub.run_gru32(pool, nets, inp_list)
+                    return (up32, ub.gru16_early(pool, nets, inp_list, up32)) if "nog16split" not in _X else up32
+                early32 = spawn(ahead, site="gru32")
             delta_flow = ub.run_fine(pool, nets, inp_list, m, up16)
             # disp_q = x - (coords1 + delta), 5 * disp2disp_gradient_xy (update.py:199) and the gradient candidates in one
             # launch; coords1 is replaced by the blend kernel's output below

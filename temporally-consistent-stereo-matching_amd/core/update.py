@@ -388,6 +388,36 @@ class BasicMultiUpdateBlock(nn.Module):
         self.gru32.step16(pool, net[2], [p], *inp[2])
         return s16.resize_bilinear(net[2], net[1].H, net[1].W, out=pool.get((id(self), "up32"), net[1].B, net[2].C, net[1].H, net[1].W, net[1].device))
 
+    # ---- gru16 split by input availability (update.py:149-153 is linear in its input channels before the gate non-linearity) ----
+    # cat(net16, pool2x(net08), interp(net32)): net16 and interp(net32) are final as soon as gru32 has run, i.e. during the previous
+    # iteration's refinement, when the GPU has idle capacity; pool2x(net08) arrives only after the hidden-state update on the critical
+    # chain.  The early share of conv_zr / conv_q goes into fp32 partial sums (tcs_conv_s16_desc.addend_ctot), the late share finishes.
+    def gru16_early(self, pool, net, inp, up32):
+        g, h = self.gru16, net[1]
+        hid, c0 = h.C, h.C + net[0].C                  # c0: first input channel of interp(net32)
+        czr = pool.get32((id(self), "czr16"), (h.B, 2 * hid, h.H, h.W), h.device)
+        if getattr(self, "_czr16_src", None) is not inp[1][0]:           # cat(cz, cr): once per frame (inp is per frame)
+            torch.cat([inp[1][0], inp[1][1]], 1, out=czr)
+            self._czr16_src = inp[1][0]
+        p_zr = pool.get32((id(self), "p16zr"), (h.B, 2 * hid, h.H, h.W), h.device)
+        p_q = pool.get32((id(self), "p16q"), (h.B, hid, h.H, h.W), h.device)
+        s16.conv2d(packed16_part(g.convzr, ((0, hid), (c0, c0 + up32.C))), [h, up32], addend=czr, out32=p_zr)
+        s16.conv2d(packed16_part(g.convq, ((c0, c0 + up32.C),)), [up32], addend=inp[1][2], out32=p_q)
+        return p_zr, p_q
+
+    def gru16_late(self, pool, net, partial):
+        """pool2x(net08) -> the rest of gru16 -> interp(net16) for gru08."""
+        p_zr, p_q = partial
+        g, h = self.gru16, net[1]
+        hid = h.C
+        p = s16.avgpool3s2(net[0], out=pool.get((id(self), "pool08"), h.B, net[0].C, h.H, h.W, h.device))
+        z = pool.get32((id(g), "z"), (h.B, hid, h.H, h.W), h.device)
+        rh = pool.get((id(g), "rh"), h.B, hid, h.H, h.W, h.device)
+        s16.gru_gates(packed16_part(g.convzr, ((hid, hid + p.C),), with_bias=False), [p], h, p_zr[:, :hid], p_zr[:, hid:], z_out=z,
+                      rh_out=rh, addend_ctot=2 * hid)
+        s16.gru_update(packed16_part(g.convq, ((0, hid + p.C),), with_bias=False), [rh, p], h, z, p_q, keep_z=g.keep_z, out=h)
+        return s16.resize_bilinear(h, net[0].H, net[0].W, out=pool.get((id(self), "up16"), h.B, h.C, net[0].H, net[0].W, h.device))
+
     def run_coarse(self, pool, net, inp, iter16=True, iter32=True, want_up16=True, up32=None):
         """gru32 -> gru16 (update.py:147-153) on S16 states, in place; returns interp(net16 -> 1/4 grid) for gru08 (or None).
         Independent of the motion encoder, which only feeds gru08.  `up32`: gru32 of this iteration already ran (run_gru32)."""
