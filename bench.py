@@ -312,7 +312,9 @@ def dry_run(a, tdist, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=60,
+                    help="timed frames (default 60 = six passes over the 10-frame clip, ~1.7 s: long enough that the box's occasional slow "
+                         "bursts (DESIGN.md section 6) enter the mean with their average weight instead of by luck)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch kernels eagerly instead of replaying HIP graphs")
