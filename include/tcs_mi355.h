@@ -202,6 +202,8 @@ int tcs_resize_bilinear(const float* x, int B, int C, int H, int W, int Ho, int 
 #define TCS_EPI_LINEAR 0         /* out = act(conv + bias + addend) * post_scale                   */
 #define TCS_EPI_GRU_ZR 1         /* first half: z = sigmoid(. + cz) -> out; second half: r = sigmoid(. + cr), out2 = r*h */
 #define TCS_EPI_GRU_Q 2          /* q = tanh(. + cq); out = blend(z, h, q)                           */
+#define TCS_EPI_BLEND9 4         /* tcs_conv2d_s16 only, Cout = 9: the nine outputs are the logits of DispRefine's softmax blend
+                                    (core/update.py:298-300), which runs in the epilogue — see tcs_conv_s16_desc.blend_*     */
 #define TCS_EPI_DECONV2X 3       /* ConvTranspose2d(k=4, stride 2, pad 1, no bias): weights from
                                     tcs_pack_deconv4x4s2_f16x3, out [B, Cout/4, 2H, 2W]   (F16X3 only)      */
 
@@ -333,6 +335,18 @@ typedef struct tcs_conv_s16_desc {
                                 accumulate into one fp32 [B, addend_ctot, H, W] tensor (LINEAR: addend = out32), and the last
                                 partial applies the real epilogue with that sum as its addend (GRU_ZR: cz = sum[:, :hidden],
                                 cr = sum[:, hidden:]) */
+    /* TCS_EPI_BLEND9 (w_head's last 1x1 convolution + tcs_softmax_blend_s16 in one launch; same arithmetic, same outputs):
+     * refined = sum_k softmax(logits)_k * cand[:, k]; delta = refined - disp; coords1 = x - refined; flow_x = coords1 - x, also
+     * written into channel blend_flow16_channel of the S16 tensor blend_flow16 (the motion features, core/update.py:126). */
+    const float* blend_cand;        /* [B, blend_cand_ctot >= 9, H, W]: the nine candidates are its first channels */
+    int blend_cand_ctot;
+    const float* blend_disp;        /* [B,1,H,W] */
+    float* blend_refined;           /* [B,1,H,W], required */
+    float* blend_delta;             /* [B,1,H,W] or NULL */
+    float* blend_coords1;           /* [B,1,H,W] or NULL */
+    float* blend_flow_x;            /* [B,1,H,W] or NULL */
+    void* blend_flow16;             /* S16 tensor or NULL */
+    int blend_flow16_groups, blend_flow16_channel;
 } tcs_conv_s16_desc;
 
 /* S16 glue of the loop: pool2x / interp (core/update.py:114-124), the up-blocks' InstanceNorm + LeakyReLU + skip

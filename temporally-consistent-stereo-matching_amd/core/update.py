@@ -577,9 +577,14 @@ class DispRefine(nn.Module):
         fused = conv16(pool, self.conv_fuse[0], [disp_f, context], act="relu")
         fused = conv16(pool, self.conv_fuse[2], [fused], act="relu")
         w = conv16(pool, self.w_head[0], [fused], act="relu")
-        logits = conv16(pool, self.w_head[2], [w], want32=True)
         coords1, flow_x = torch.empty_like(disp), torch.empty_like(disp)
-        refined, delta = s16.softmax_blend(logits, cand9, disp, coords1, flow_x, flow_x_s16=motion, flow_x_channel=127)
+        if "noblendfuse" not in _X:
+            # the blend runs as the epilogue of w_head's 1x1 convolution: one launch less on the iteration's critical chain
+            refined, delta = s16.conv1x1_blend(packed16(self.w_head[2]), [w], cand9, disp, coords1, flow_x, flow_x_s16=motion,
+                                               flow_x_channel=127)
+        else:
+            logits = conv16(pool, self.w_head[2], [w], want32=True)
+            refined, delta = s16.softmax_blend(logits, cand9, disp, coords1, flow_x, flow_x_s16=motion, flow_x_channel=127)
         mask = None
         if want_mask:
             m = conv16(pool, self.mask[0], [fused], act="relu")

@@ -59,6 +59,9 @@ struct S16Args {
     int out_ctot, out_coff;
     int npx, nct;
     int npatch, csplit;                 // block -> (patch, cout tile) mapping, see s16_block_tile()
+    // TCS_EPI_BLEND9: DispRefine's softmax blend on the nine outputs (tcs_mi355.h)
+    const float* bl_cand; int bl_cand_ctot; const float* bl_disp;
+    float* bl_refined; float* bl_delta; float* bl_coords1; float* bl_flow; _Float16* bl_f16; int bl_f16_groups, bl_f16_ch;
     int ablate;                         // diagnostic builds only (-DTCS_S16_ABLATE, tools/conv_s16_ablate.py): bit 0 skip the
                                         // input DMA, bit 1 skip the weight DMA, bit 2 skip operand reads + MFMAs (timing only)
 };
@@ -124,6 +127,36 @@ __device__ __forceinline__ void s16_epilogue_tile(const S16Args& a, int b, int c
                     _Float16* o = a.out16 + s16_unit(b, a.out16_groups, a.out16_goff + g, 0, Hp, Wp, py, px) + sub4;
                     s16_store4(o, (size_t)Hp * Wp * 8, &v[4 * q], a.Cout - c_first);
                 }
+            }
+        }
+    } else if (EPI == TCS_EPI_BLEND9) {
+        // Cout = 9, one tile: lane (pixel, half 0) holds logits 0-3 in v[0..3] and logit 8 in v[4], its partner lane + 32 (same pixel)
+        // holds logits 4-7 in v[0..3].  Both halves are active together (same pixel), so the exchange below is well defined.
+        float lg[9];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { lg[j] = v[j]; lg[4 + j] = __shfl_xor(v[j], 32); }
+        lg[8] = v[4];
+        if ((co0 & 4) == 0) {                           // the lower half-wave finishes the pixel
+            float m = -INFINITY, sum = 0.f, r = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) m = fmaxf(m, lg[k]);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) { lg[k] = expf(lg[k] - m); sum += lg[k]; }
+            const float* c = a.bl_cand + (size_t)b * a.bl_cand_ctot * HW + pix;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) r += (lg[k] / sum) * c[(size_t)k * HW];
+            const size_t o = (size_t)b * HW + pix;
+            a.bl_refined[o] = r;
+            if (a.bl_delta) a.bl_delta[o] = r - a.bl_disp[o];
+            const float xf = (float)px, c1 = xf - r;
+            if (a.bl_coords1) a.bl_coords1[o] = c1;
+            if (a.bl_flow) a.bl_flow[o] = c1 - xf;
+            if (a.bl_f16) {
+                half2_t hi, lo;
+                s16_split2(c1 - xf, 0.f, hi, lo);
+                _Float16* o16 = a.bl_f16 + s16_unit(b, a.bl_f16_groups, a.bl_f16_ch >> 3, 0, Hp, Wp, py, px) + (a.bl_f16_ch & 7);
+                o16[0] = hi[0];
+                o16[(size_t)Hp * Wp * 8] = lo[0];
             }
         }
     } else if (EPI == TCS_EPI_DECONV2X) {
@@ -626,7 +659,9 @@ int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
     a.npx = 0; a.nct = 0; a.npatch = 0;
     a.csplit = (d->tile_cfg / 100000) % 10;            // 0 = cout tile fastest (one weight slice per XCD)
     a.ablate = d->tile_cfg / 1000000;                  // honoured by -DTCS_S16_ABLATE builds only
-    if (!a.out16 && !a.out32) return TCS_EINVAL;
+    a.bl_cand = nullptr; a.bl_cand_ctot = 0; a.bl_disp = nullptr; a.bl_refined = nullptr; a.bl_delta = nullptr; a.bl_coords1 = nullptr;
+    a.bl_flow = nullptr; a.bl_f16 = nullptr; a.bl_f16_groups = 0; a.bl_f16_ch = 0;
+    if (!a.out16 && !a.out32 && d->epilogue != TCS_EPI_BLEND9) return TCS_EINVAL;
     // the packed weight image pads K to a multiple of 64 channels (tcs_conv_packed_floats_f16x3): nk may not exceed it
     const int kpack = ((d->Cin + 63) / 64) * 4;
     int kst = 1;
@@ -670,6 +705,14 @@ int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
             if (stride == 2 && d->ksize == 1) return launch_s16_cfg<1, 2, TCS_EPI_LINEAR>(a, cfg, s);
             if (stride == 2) return launch_s16_cfg<3, 2, TCS_EPI_LINEAR>(a, cfg, s);
             return d->ksize == 3 ? launch_s16_cfg<3, 1, TCS_EPI_LINEAR>(a, cfg, s) : launch_s16_cfg<1, 1, TCS_EPI_LINEAR>(a, cfg, s);
+        case TCS_EPI_BLEND9:
+            if (d->ksize != 1 || stride != 1 || d->Cout != 9 || !d->blend_cand || d->blend_cand_ctot < 9 || !d->blend_refined) return TCS_EINVAL;
+            if (d->blend_delta && !d->blend_disp) return TCS_EINVAL;
+            if (d->blend_flow16 && (d->blend_flow16_channel < 0 || d->blend_flow16_channel >= 8 * d->blend_flow16_groups)) return TCS_EINVAL;
+            a.bl_cand = d->blend_cand; a.bl_cand_ctot = d->blend_cand_ctot; a.bl_disp = d->blend_disp;
+            a.bl_refined = d->blend_refined; a.bl_delta = d->blend_delta; a.bl_coords1 = d->blend_coords1; a.bl_flow = d->blend_flow_x;
+            a.bl_f16 = reinterpret_cast<_Float16*>(d->blend_flow16); a.bl_f16_groups = d->blend_flow16_groups; a.bl_f16_ch = d->blend_flow16_channel;
+            return launch_s16_cfg<1, 1, TCS_EPI_BLEND9>(a, cfg, s);
         case TCS_EPI_DECONV2X:
             if (d->ksize != 3 || !a.out16 || d->Cout % 32 != 0) return TCS_EINVAL;
             a.hidden = d->Cout / 4;

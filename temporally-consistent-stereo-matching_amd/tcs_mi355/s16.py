@@ -20,6 +20,7 @@ from . import native as nv
 from .ops import ACT, EPI_GRU_Q, EPI_GRU_ZR, EPI_LINEAR, MATH_F16X3, PackedConv
 
 EPI_DECONV2X = 3
+EPI_BLEND9 = 4
 
 
 def groups_for(C_: int) -> int:
@@ -317,6 +318,26 @@ def softmax_blend(logits9, cand9, disp_q, coords1, flow_x, flow_x_s16: Optional[
                                             nv.ptr(refined), nv.ptr(delta), nv.ptr(coords1), nv.ptr(flow_x),
                                             None if flow_x_s16 is None else flow_x_s16.ptr(), 0 if flow_x_s16 is None else flow_x_s16.G,
                                             int(flow_x_channel), nv.stream()), "tcs_softmax_blend_s16")
+    return refined, delta
+
+
+def conv1x1_blend(pc: PackedConv, srcs: Sequence[S16], cand9, disp_q, coords1, flow_x, flow_x_s16: Optional[S16] = None,
+                  flow_x_channel: int = 0, refined=None, delta=None, tile_cfg: int = 0):
+    """w_head's last 1x1 convolution (-> 9 logits) with DispRefine's softmax blend as its epilogue (update.py:297-300 +
+    tc_stereo.py:198-202): one launch instead of conv + `softmax_blend`, same arithmetic and outputs -> (refined, delta)."""
+    if pc.cout != 9 or pc.ksize != 1:
+        raise ValueError("conv1x1_blend: a 1x1 convolution with 9 outputs")
+    d = _desc(pc, srcs)
+    refined = torch.empty(d.B, 1, d.H, d.W, dtype=torch.float32, device=srcs[0].device) if refined is None else refined
+    delta = torch.empty_like(refined) if delta is None else delta
+    d.epilogue, d.act, d.post_scale = EPI_BLEND9, ACT["none"], 1.0
+    d.blend_cand, d.blend_cand_ctot, d.blend_disp = nv.ptr(cand9, "cand"), int(cand9.shape[1]), nv.ptr(disp_q, "disp")
+    d.blend_refined, d.blend_delta = nv.ptr(refined, "refined"), nv.ptr(delta, "delta")
+    d.blend_coords1, d.blend_flow_x = nv.ptr(coords1, "coords1"), nv.ptr(flow_x, "flow_x")
+    if flow_x_s16 is not None:
+        d.blend_flow16, d.blend_flow16_groups, d.blend_flow16_channel = flow_x_s16.ptr(), flow_x_s16.G, int(flow_x_channel)
+    d.tile_cfg = int(tile_cfg)
+    nv.check(nv.lib().tcs_conv2d_s16(C.byref(d), nv.stream()), "tcs_conv2d_s16[blend9]")
     return refined, delta
 
 

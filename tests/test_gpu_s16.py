@@ -262,6 +262,36 @@ def test_glue_s16_vs_torch(dev):
     assert float(s16.from_s16(buf, 128)[:, :127].abs().max()) == 0
 
 
+def test_conv1x1_blend_equals_conv_then_blend(dev):
+    """TCS_EPI_BLEND9: w_head's last 1x1 convolution with the softmax blend as its epilogue must give exactly what the two
+    launches give (same logits, same formula): refined, delta, coords1, flow_x and the flow channel of the S16 buffer."""
+    from tcs_mi355 import ops, s16
+    gen = torch.Generator().manual_seed(31)
+    for B, H, W in ((1, 11, 45), (2, 9, 70)):
+        w = torch.randn(9, 128, 1, 1, generator=gen) * 0.1
+        b = torch.randn(9, generator=gen) * 0.1
+        x16 = s16.to_s16(D(torch.randn(B, 128, H, W, generator=gen), dev))
+        cand = D(torch.rand(B, 9, H, W, generator=gen) * 50, dev)
+        disp = D(torch.rand(B, 1, H, W, generator=gen) * 50, dev)
+        pc = ops.pack_conv(D(w, dev), D(b, dev), "f16x3")
+        outs = []
+        for fused in (False, True):
+            c1, fx = torch.empty(B, 1, H, W, device=dev), torch.empty(B, 1, H, W, device=dev)
+            buf = s16.zeros(B, 128, H, W, dev)
+            if fused:
+                r, dl = s16.conv1x1_blend(pc, [x16], cand, disp, c1, fx, flow_x_s16=buf, flow_x_channel=127)
+            else:
+                logits = s16.conv2d(pc, [x16], want32=True)[1]
+                r, dl = s16.softmax_blend(logits, cand, disp, c1, fx, flow_x_s16=buf, flow_x_channel=127)
+            outs.append((r, dl, c1, fx, buf.data.clone()))
+        for a_, b_ in zip(*outs):
+            assert bool((a_ == b_).all())
+        # and against fp64 arithmetic
+        logits = F.conv2d(x16.float().double().cpu(), w.double(), b.double())
+        ref = (torch.softmax(logits, 1) * cand.double().cpu()).sum(1, keepdim=True)
+        assert maxdiff(outs[1][0], ref) <= 2e-4
+
+
 def test_hidden_update_fused_vs_torch(dev):
     """tcs_hidden_update_s16 (HiddenstateUpdater, update.py:57-68, one launch) against fp64 PyTorch, ragged grid, batch 2."""
     from tcs_mi355 import s16

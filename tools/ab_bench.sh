@@ -6,7 +6,7 @@ rounds=$1; shift
 for r in $(seq 1 $rounds); do
   for v in "$@"; do
     x=$v; [ "$v" = "-" ] && x=""
-    ms=$(TCS_MI355_X=$x python bench.py --steps 10 --warmup 3 --no-cpu-baseline --batched-leg 0 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.readline())['ms_per_step'])")
+    ms=$(TCS_MI355_X=$x python bench.py --steps 20 --warmup 3 --no-cpu-baseline --batched-leg 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], 'per-step min/median/max', d['step_ms_min_median_max'])")
     echo "round $r variant [$v] ms_per_step $ms"
   done
 done
