@@ -276,6 +276,11 @@ def spawn_ranks(a, argv):
     the GPU (a process that has initialised HIP must not exec or fork GPU workers on this pool)."""
     import socket
     import subprocess
+    if not a.dry_run:
+        import torch
+        have = torch.cuda.device_count()             # counting devices does not initialise HIP on this image
+        if have < a.gpus:
+            raise SystemExit(f"bench.py --gpus {a.gpus}: this box exposes {have} GPU(s); one rank per GPU is the only supported layout")
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
@@ -285,11 +290,25 @@ def spawn_ranks(a, argv):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0)
+    # a rank that dies (bad device, import error) must not leave the others waiting in the rendezvous for its time-out
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()                    # exactly the processes started above
+            break
+        time.sleep(0.2)
+    rcs = [p.wait() for p in procs]
+    reader.join(timeout=5)
+    sys.stdout.write("".join(out0))
     sys.stdout.flush()
-    if any(rcs):
+    if failed or any(rcs):
         raise SystemExit(f"rank return codes {rcs}")
 
 
