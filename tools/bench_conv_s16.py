@@ -30,6 +30,8 @@ SHAPES = [  # name, (cins...), cout, k, H, W, epilogue, stride
     ("1x1 27->96", (27,), 96, 1, 120, 160, "lin", 1),
     ("1x1 96->96", (96,), 96, 1, 120, 160, "lin", 1),
     ("1x1 128->9", (128,), 9, 1, 120, 160, "lin", 1),
+    ("head 256->1", (256,), 1, 3, 120, 160, "lin", 1),
+    ("head 128->2", (128,), 2, 3, 120, 160, "lin", 1),
     ("s2 64->96", (64,), 96, 3, 120, 160, "lin", 2),
     ("deconv 128->96", (128,), 96, 3, 30, 40, "deconv", 1),
 ]
