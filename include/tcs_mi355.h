@@ -291,6 +291,12 @@ size_t tcs_s16_bytes(int B, int C, int H, int W);
  * (core/update.py:27-35,58-67,78-86,155-158).  Reads and clears the word; SYNCHRONISES the device (call it once per frame or
  * sequence, outside any graph capture). */
 int tcs_s16_flags(unsigned int* flags_out);
+/* The same read-and-clear, one word per producing source file of the library, for locating a violation:
+ * [0] tcs_conv_s16.hip (S16 convolutions, GRU / deconv / blend epilogues, tcs_s16_from_f32), [1] tcs_s16_ops.hip (pool, interp, InstanceNorm,
+ * propagate stencil, fused HiddenstateUpdater), [2] tcs_conv.hip (fp32-MFMA and 7x7 convolutions with an S16 epilogue),
+ * [3] tcs_conv_f16.hip (fp32-tensor fp16-split convolutions with an S16 epilogue), [4] tcs_stencil.hip (the stand-alone blend kernel's flow channel). */
+#define TCS_S16_FLAG_UNITS 5
+int tcs_s16_flags_detail(unsigned int* per_unit);
 /* x [B,C,H,W] fp32 -> groups [group_offset, group_offset + 2*ceil(C/16)) of an S16 tensor with groups_total groups */
 int tcs_s16_from_f32(const float* x, int B, int C, int H, int W, void* s16, int groups_total, int group_offset, tcs_stream_t stream);
 /* channels [8*group_offset, 8*group_offset + C) of an S16 tensor -> out [B,C,H,W] fp32 (hi + lo) */

@@ -563,15 +563,24 @@ int tcs_s16_flag_take_stencil(unsigned int*);
 
 extern "C" {
 
+int tcs_s16_flags_detail(unsigned int* per_unit /* [TCS_S16_FLAG_UNITS] */) {
+    if (!per_unit) return TCS_EINVAL;
+    if (hipDeviceSynchronize() != hipSuccess) return TCS_ELAUNCH;
+    for (int i = 0; i < TCS_S16_FLAG_UNITS; ++i) per_unit[i] = 0;
+    int rc = tcs_s16_flag_take_conv_s16(&per_unit[0]);
+    if (rc == TCS_OK) rc = tcs_s16_flag_take_s16_ops(&per_unit[1]);
+    if (rc == TCS_OK) rc = tcs_s16_flag_take_conv(&per_unit[2]);
+    if (rc == TCS_OK) rc = tcs_s16_flag_take_conv_f16(&per_unit[3]);
+    if (rc == TCS_OK) rc = tcs_s16_flag_take_stencil(&per_unit[4]);
+    return rc;
+}
+
 int tcs_s16_flags(unsigned int* flags_out) {
     if (!flags_out) return TCS_EINVAL;
-    if (hipDeviceSynchronize() != hipSuccess) return TCS_ELAUNCH;
+    unsigned int u[TCS_S16_FLAG_UNITS];
+    const int rc = tcs_s16_flags_detail(u);
     unsigned int v = 0;
-    int rc = tcs_s16_flag_take_conv_s16(&v);
-    if (rc == TCS_OK) rc = tcs_s16_flag_take_s16_ops(&v);
-    if (rc == TCS_OK) rc = tcs_s16_flag_take_conv(&v);
-    if (rc == TCS_OK) rc = tcs_s16_flag_take_conv_f16(&v);
-    if (rc == TCS_OK) rc = tcs_s16_flag_take_stencil(&v);
+    for (int i = 0; i < TCS_S16_FLAG_UNITS; ++i) v |= u[i];
     *flags_out = v;
     return rc;
 }

@@ -3,6 +3,9 @@ core/utils/frame_utils.py reads for the evaluation configs, restated with numpy 
 imageio or scipy dependency) so that BASELINE configs 3 (TartanAir) and 5 (KITTI raw) can run when the
 data is present on the box.  Every pose reader returns WORLD->CAMERA 4x4 matrices, the convention
 `TCStereo.forward` expects in params['T'] (geo_utils.py:148-155).
+
+Pinned to the reference: tools/make_goldens_formats.py runs the reference's own readers on constructed files and
+tests/test_host.py::test_formats_match_reference_fixtures checks these functions against what they returned.
 """
 from __future__ import annotations
 
@@ -101,6 +104,13 @@ def read_pfm(path: str) -> np.ndarray:
         data = np.frombuffer(f.read(), dtype=("<f4" if scale < 0 else ">f4"))
     shape = (h, w, 3) if kind == b"PF" else (h, w)
     return np.flipud(data[: int(np.prod(shape))].reshape(shape)).astype(np.float32)
+
+
+def read_gen_pfm(path: str) -> np.ndarray:
+    """What the reference's `read_gen` returns for a .pfm (frame_utils.py:223-228): float32, and for a colour file the last
+    channel dropped."""
+    a = read_pfm(path)
+    return a if a.ndim == 2 else a[:, :, :-1]
 
 
 def write_pfm(path: str, img: np.ndarray) -> None:

@@ -97,6 +97,7 @@ SIGNATURES = {
     "tcs_conv2d": (c_int, [C.POINTER(ConvDesc), c_fp]),
     "tcs_s16_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
     "tcs_s16_flags": (c_int, [C.POINTER(C.c_uint)]),
+    "tcs_s16_flags_detail": (c_int, [C.POINTER(C.c_uint)]),
     "tcs_s16_from_f32": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_int, c_fp]),
     "tcs_s16_to_f32": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp]),
     "tcs_conv2d_s16": (c_int, [C.POINTER(ConvS16Desc), c_fp]),

@@ -205,8 +205,8 @@ def test_bench_spawns_its_own_ranks():
 
 def test_tartanair_folder_and_checkpoint_loaders(tmp_path, key_shapes):
     """BASELINE configs[2] plumbing on a constructed 2-frame trajectory folder: file pairing, PNG decoding, depth->disparity,
-    pose parsing, and the weights-only checkpoint path with DataParallel-style `module.` keys (parity unpinned by reference
-    outputs: the reference's readers need cv2 / imageio, which are absent here)."""
+    pose parsing, and the weights-only checkpoint path with DataParallel-style `module.` keys.  (The readers themselves are
+    pinned to the reference's outputs by test_formats_match_reference_fixtures; no dataset or checkpoint exists offline.)"""
     from PIL import Image
     from tcs_mi355 import harness
     from tcs_mi355.weights import synth_state_dict
@@ -249,9 +249,8 @@ def test_tartanair_folder_and_checkpoint_loaders(tmp_path, key_shapes):
 
 
 def test_formats_known_answers(tmp_path):
-    """N2 file formats.  The reference readers (core/utils/frame_utils.py) cannot be imported here (cv2 /
-    imageio are absent), so these are known-answer checks against scipy's Rotation — the function the
-    reference itself calls (frame_utils.py:244) — and round trips: parity unpinned by reference outputs."""
+    """N2 file formats: known-answer checks against scipy's Rotation — the function the reference itself calls
+    (frame_utils.py:244) — and round trips.  The reference-generated vectors are in test_formats_match_reference_fixtures."""
     from scipy.spatial.transform import Rotation
     from tcs_mi355 import formats
     rng = np.random.default_rng(0)
@@ -292,3 +291,34 @@ def test_formats_known_answers(tmp_path):
     be = tmp_path / "be.pfm"
     be.write_bytes(b"Pf\n2 2\n1.0\n" + np.array([[3, 4], [1, 2]], ">f4").tobytes())
     assert np.array_equal(formats.read_pfm(str(be)), np.array([[1, 2], [3, 4]], np.float32))
+
+
+def test_formats_match_reference_fixtures(tmp_path):
+    """N2 pinned to the reference: tests/golden/formats.npz holds constructed input files (as bytes) and what the REFERENCE's
+    readers (core/utils/frame_utils.py, imported by tools/make_goldens_formats.py with stub cv2 / imageio modules) returned for
+    them.  tcs_mi355/formats.py and the harness' PNG reader must reproduce those outputs: poses to 1e-12 (same float64
+    algebra, scipy vs a closed-form quaternion matrix), everything else exactly."""
+    from tcs_mi355 import formats, harness
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "formats.npz")))
+
+    def put(name, key):
+        p = tmp_path / name
+        p.write_bytes(g[key].tobytes())
+        return str(p)
+
+    got = np.stack(formats.read_tartanair_extrinsic(put("pose_left.txt", "tartanair_pose_txt")))
+    assert got.shape == g["tartanair_pose_out"].shape and np.abs(got - g["tartanair_pose_out"]).max() <= 1e-12
+    disp, valid = formats.read_disp_tartanair(put("000000_left_depth.npy", "tartanair_depth_npy"))
+    assert disp.dtype == g["tartanair_disp_out"].dtype and np.array_equal(disp, g["tartanair_disp_out"])
+    assert np.array_equal(valid, g["tartanair_valid_out"])
+    for name in ("pfm_le", "pfm_be", "pfm_color"):
+        a = formats.read_pfm(put(name + ".pfm", name + "_file"))
+        assert a.shape == g[name + "_out"].shape and np.array_equal(a, g[name + "_out"]), name
+        b = formats.read_gen_pfm(str(tmp_path / (name + ".pfm")))
+        assert b.shape == g[name + "_gen_out"].shape and np.array_equal(b, g[name + "_gen_out"]), name
+    got = np.stack(formats.read_kitti_extrinsic(put("poses.txt", "kitti_pose_txt")))
+    assert np.abs(got - g["kitti_pose_out"]).max() <= 1e-12
+    got = np.stack(formats.read_sceneflow_pose(put("camera_data.txt", "sceneflow_pose_txt")))
+    assert got.shape == g["sceneflow_pose_out"].shape and np.abs(got - g["sceneflow_pose_out"]).max() <= 1e-12
+    img = harness._read_rgb(put("000000_left.png", "png_file"))
+    assert img.dtype == np.float32 and np.array_equal(img, g["png_out"])
