@@ -353,6 +353,12 @@ typedef struct tcs_conv_s16_desc {
     float* blend_flow_x;            /* [B,1,H,W] or NULL */
     void* blend_flow16;             /* S16 tensor or NULL */
     int blend_flow16_groups, blend_flow16_channel;
+    /* LINEAR: two layers that read the same input as ONE launch (weights concatenated along Cout): output channels
+     * [out16_split, Cout) go to groups [0, ...) of the second S16 tensor `out16b` instead of `out16`
+     * (DispGradPredictor's residual_head[0] and conv_out[0] both read x4_up, core/update.py:212-214).
+     * out16_split must be a multiple of 32; NULL = single output. */
+    void* out16b;
+    int out16b_groups, out16_split;
 } tcs_conv_s16_desc;
 
 /* S16 glue of the loop: pool2x / interp (core/update.py:114-124), the up-blocks' InstanceNorm + LeakyReLU + skip

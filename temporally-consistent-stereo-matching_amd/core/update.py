@@ -78,6 +78,22 @@ def packed16_part(conv: nn.Conv2d, cin_slices, with_bias: bool = True) -> ops.Pa
     return hit[1]
 
 
+def packed16_cat(convs) -> ops.PackedConv:
+    """fp16-split packing of several layers that read the same input, concatenated along Cout (weights and biases): one
+    launch, the outputs split again by channel range in the epilogue (tcs_conv_s16_desc.out16b)."""
+    key = tuple((c.weight.data_ptr(), c.weight._version, None if c.bias is None else (c.bias.data_ptr(), c.bias._version)) for c in convs)
+    host = convs[0]
+    cache = host.__dict__.setdefault("_tcs_cat", {})
+    ids = tuple(id(c) for c in convs)
+    hit = cache.get(ids)
+    if hit is None or hit[0] != key:
+        w = torch.cat([c.weight.detach() for c in convs], 0).contiguous()
+        b = torch.cat([(c.bias.detach() if c.bias is not None else torch.zeros(c.out_channels, device=c.weight.device)) for c in convs], 0).contiguous()
+        hit = (key, ops.pack_conv(w, b, "f16x3"))
+        cache[ids] = hit
+    return hit[1]
+
+
 def pool_of(module) -> s16.S16Pool:
     """The S16 buffer pool of the model a module belongs to (TCStereo shares one; a stand-alone module gets its own)."""
     p = getattr(module, "_s16pool", None)
@@ -524,12 +540,21 @@ class DispGradPredictor(nn.Module):
         x8_up = up_block16(pool, self.conv_16_8, x16, x8)
         x4_up = up_block16(pool, self.conv_8_4, x8_up, x4)
 
-        def head():
+        rh0, co0 = self.residual_head[0], self.conv_out[0]
+        if "noheadfuse" not in _X and rh0.out_channels % 32 == 0:
+            # residual_head[0] and conv_out[0] read the same x4_up (update.py:212-214): one 64 -> 128 + 64 launch whose epilogue
+            # sends the two channel ranges to their own S16 tensors — one launch and a fork / join less per iteration
+            h = pool.get((id(rh0), "o"), x4_up.B, rh0.out_channels, x4_up.H, x4_up.W, x4_up.device)
+            ctx = pool.get((id(co0), "o"), x4_up.B, co0.out_channels, x4_up.H, x4_up.W, x4_up.device)
+            s16.conv2d(packed16_cat([rh0, co0]), [x4_up], act="relu", out16=h, out16b=ctx, out16_split=rh0.out_channels)
             # (5*grad + residual) / 5 (update.py:213) in the epilogue of the last conv: addend = 5*grad, scale = 1/5
-            h = conv16(pool, self.residual_head[0], [x4_up], act="relu")
+            return conv16(pool, self.residual_head[2], [h], addend=g5, post_scale=0.2, want32=True), ctx
+
+        def head():
+            h = conv16(pool, rh0, [x4_up], act="relu")
             return conv16(pool, self.residual_head[2], [h], addend=g5, post_scale=0.2, want32=True)
 
-        grad, ctx = fork_join([head, lambda: conv16(pool, self.conv_out[0], [x4_up], act="relu")], site="heads")
+        grad, ctx = fork_join([head, lambda: conv16(pool, co0, [x4_up], act="relu")], site="heads")
         return grad, ctx
 
 

@@ -62,6 +62,7 @@ struct S16Args {
     // TCS_EPI_BLEND9: DispRefine's softmax blend on the nine outputs (tcs_mi355.h)
     const float* bl_cand; int bl_cand_ctot; const float* bl_disp;
     float* bl_refined; float* bl_delta; float* bl_coords1; float* bl_flow; _Float16* bl_f16; int bl_f16_groups, bl_f16_ch;
+    _Float16* out16b; int out16b_groups, out16_split;   // LINEAR: channels >= out16_split go to this second S16 tensor (tcs_mi355.h)
     int ablate;                         // diagnostic builds only (-DTCS_S16_ABLATE, tools/conv_s16_ablate.py): bit 0 skip the
                                         // input DMA, bit 1 skip the weight DMA, bit 2 skip operand reads + MFMAs (timing only)
 };
@@ -124,7 +125,10 @@ __device__ __forceinline__ void s16_epilogue_tile(const S16Args& a, int b, int c
             for (int q = 0; q < 4; ++q) {
                 const int g = (co0 >> 3) + q, c_first = co0 + 8 * q;  // 4 consecutive channels c_first .. c_first + 3
                 if (c_first < a.Cout) {
-                    _Float16* o = a.out16 + s16_unit(b, a.out16_groups, a.out16_goff + g, 0, Hp, Wp, py, px) + sub4;
+                    // two layers in one launch: a tile (32 channels) lies wholly on one side of out16_split (a multiple of 32)
+                    const bool second = a.out16b != nullptr && c_first >= a.out16_split;
+                    _Float16* o = second ? a.out16b + s16_unit(b, a.out16b_groups, g - (a.out16_split >> 3), 0, Hp, Wp, py, px) + sub4
+                                         : a.out16 + s16_unit(b, a.out16_groups, a.out16_goff + g, 0, Hp, Wp, py, px) + sub4;
                     s16_store4(o, (size_t)Hp * Wp * 8, &v[4 * q], a.Cout - c_first);
                 }
             }
@@ -656,6 +660,11 @@ int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
     a.keep_z = d->blend_keep_z; a.hidden = 0;
     a.out16 = reinterpret_cast<_Float16*>(d->out16); a.out16_groups = d->out16_groups; a.out16_goff = d->out16_group_offset;
     a.out32 = d->out32; a.out_ctot = d->out_ctot; a.out_coff = d->out_coff;
+    a.out16b = reinterpret_cast<_Float16*>(d->out16b); a.out16b_groups = d->out16b_groups; a.out16_split = d->out16_split;
+    if (a.out16b) {
+        if (d->epilogue != TCS_EPI_LINEAR || !a.out16 || a.out16_split <= 0 || a.out16_split % 32 != 0 || a.out16_split >= d->Cout) return TCS_EINVAL;
+        if (a.out16b_groups < (d->Cout - a.out16_split + 7) / 8) return TCS_EINVAL;
+    }
     a.npx = 0; a.nct = 0; a.npatch = 0;
     a.csplit = (d->tile_cfg / 100000) % 10;            // 0 = cout tile fastest (one weight slice per XCD)
     a.ablate = d->tile_cfg / 1000000;                  // honoured by -DTCS_S16_ABLATE builds only
@@ -684,7 +693,8 @@ int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
         }
     if (ktot > kpack) return TCS_EINVAL;
     a.nk = ktot;
-    const int outG = a.out16 ? ((d->epilogue == TCS_EPI_GRU_ZR ? d->Cout / 2 : (d->epilogue == TCS_EPI_DECONV2X ? d->Cout / 4 : d->Cout)) + 7) / 8 : 0;
+    const int out16_ch = d->epilogue == TCS_EPI_GRU_ZR ? d->Cout / 2 : (d->epilogue == TCS_EPI_DECONV2X ? d->Cout / 4 : (a.out16b ? a.out16_split : d->Cout));
+    const int outG = a.out16 ? (out16_ch + 7) / 8 : 0;
     if (a.out16 && (a.out16_goff < 0 || a.out16_goff + outG > a.out16_groups)) return TCS_EINVAL;
     if (a.out32 && d->epilogue == TCS_EPI_LINEAR && (d->out_coff < 0 || d->out_coff + d->Cout > d->out_ctot)) return TCS_EINVAL;
     hipStream_t s = tcs_stream(stream);

@@ -54,6 +54,7 @@ class ConvS16Desc(C.Structure):
         ("tile_cfg", c_int), ("addend_ctot", c_int),
         ("blend_cand", c_fp), ("blend_cand_ctot", c_int), ("blend_disp", c_fp), ("blend_refined", c_fp), ("blend_delta", c_fp),
         ("blend_coords1", c_fp), ("blend_flow_x", c_fp), ("blend_flow16", c_fp), ("blend_flow16_groups", c_int), ("blend_flow16_channel", c_int),
+        ("out16b", c_fp), ("out16b_groups", c_int), ("out16_split", c_int),
     ]
 
 

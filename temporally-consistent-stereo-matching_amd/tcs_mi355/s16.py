@@ -159,10 +159,12 @@ def _out_grid(s: S16, stride: int):
 
 def conv2d(pc: PackedConv, srcs: Sequence[S16], act: str = "none", addend: Optional[torch.Tensor] = None, post_scale: float = 1.0,
            out16: Optional[S16] = None, out16_group_offset: int = 0, out32: Optional[torch.Tensor] = None, out_coff: int = 0,
-           stride: int = 1, want32: bool = False, tile_cfg: int = 0, addend16: Optional[S16] = None, addend_ctot: int = 0):
+           stride: int = 1, want32: bool = False, tile_cfg: int = 0, addend16: Optional[S16] = None, addend_ctot: int = 0,
+           out16b: Optional[S16] = None, out16_split: int = 0):
     """act(conv(cat(srcs)) + bias + addend) * post_scale -> S16 (`out16`, allocated when neither output is given)
     and/or fp32 NCHW (`out32`, or allocated when want32).  Returns (out16, out32).  `addend_ctot` > Cout: `addend` is a
-    channel slice of a [B, addend_ctot, Ho, Wo] tensor (pass the sliced view)."""
+    channel slice of a [B, addend_ctot, Ho, Wo] tensor (pass the sliced view).  `out16b`: output channels from `out16_split`
+    (a multiple of 32) on go to this second S16 tensor — two layers over the same input as one launch."""
     d = _desc(pc, srcs, stride)
     Ho, Wo = _out_grid(srcs[0], stride)
     if out32 is None and want32:
@@ -183,6 +185,10 @@ def conv2d(pc: PackedConv, srcs: Sequence[S16], act: str = "none", addend: Optio
         d.addend16, d.addend16_groups = addend16.ptr(), addend16.G
     if out16 is not None:
         d.out16, d.out16_groups, d.out16_group_offset = out16.ptr(), out16.G, int(out16_group_offset)
+    if out16b is not None:
+        if out16 is None or (out16b.B, out16b.H, out16b.W) != (d.B, Ho, Wo):
+            raise ValueError("conv2d: `out16b` needs `out16` and the same grid")
+        d.out16b, d.out16b_groups, d.out16_split = out16b.ptr(), out16b.G, int(out16_split)
     if out32 is not None:
         d.out32, d.out_ctot, d.out_coff = nv.ptr(out32, "out32"), int(out32.shape[1]), int(out_coff)
     d.tile_cfg = int(tile_cfg)

@@ -337,3 +337,25 @@ def test_domain_guard_flags(dev):
     w = torch.full((32, 16, 3, 3), 500.0)
     s16.conv2d(ops.pack_conv(D(w, dev), None, "f16x3"), [s16.to_s16(D(torch.full((1, 16, 8, 32), 10.0), dev))])
     assert s16.take_flags() & 1
+
+
+def test_conv2d_s16_two_outputs_equal_separate_launches(dev):
+    """tcs_conv_s16_desc.out16b: two layers over the same input as one launch (residual_head[0] + conv_out[0] of the gradient
+    predictor, core/update.py:212-214).  Same K loop per output channel, so the result is bit-equal to the two separate launches."""
+    from tcs_mi355 import ops, s16
+    gen = torch.Generator().manual_seed(5)
+    for (ca, cb, cin, H, W) in ((128, 64, 64, 13, 37), (32, 96, 48, 9, 33)):
+        x = torch.randn(1, cin, H, W, generator=gen)
+        wa, wb = (torch.randn(c, cin, 3, 3, generator=gen) * (2.0 / (9 * cin)) ** 0.5 for c in (ca, cb))
+        ba, bb = torch.randn(ca, generator=gen) * 0.1, torch.randn(cb, generator=gen) * 0.1
+        x16 = s16.to_s16(D(x, dev))
+        # the separate launches must use the joint weight scale to be bit-comparable: pack each from the joint tensor's slices
+        pc = ops.pack_conv(D(torch.cat([wa, wb]), dev), D(torch.cat([ba, bb]), dev), "f16x3")
+        oa, ob = s16.zeros(1, ca, H, W, dev), s16.zeros(1, cb, H, W, dev)
+        s16.conv2d(pc, [x16], act="relu", out16=oa, out16b=ob, out16_split=ca)
+        whole, _ = s16.conv2d(pc, [x16], act="relu")
+        assert torch.equal(oa.float(), whole.float()[:, :ca]) and torch.equal(ob.float(), whole.float()[:, ca:])
+        for o, w, b in ((oa, wa, ba), (ob, wb, bb)):
+            assert maxdiff(o.float(), torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))) <= 2e-5
+    with pytest.raises(RuntimeError):          # the split must be tile aligned
+        s16.conv2d(pc, [x16], out16=oa, out16b=ob, out16_split=16)

@@ -60,6 +60,22 @@ def test_conv_desc_layout_matches_header():
     assert fields == [f[0] for f in native.ConvDesc._fields_]
 
 
+def test_conv_s16_desc_layout_matches_header():
+    """ctypes mirror of struct tcs_conv_s16_desc: same field order as the header."""
+    from tcs_mi355 import native
+    header = open(os.path.join(ROOT, "include", "tcs_mi355.h")).read()
+    body = header[header.index("typedef struct tcs_conv_s16_desc {"):header.index("} tcs_conv_s16_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(","):
+            fields.append(re.sub(r"\[.*?\]", "", part.strip().split()[-1].lstrip("*")))
+    assert fields == [f[0] for f in native.ConvS16Desc._fields_]
+
+
 @pytest.mark.parametrize("tag,kw", [("shared_backbone", {}), ("separate_fnet", dict(shared_backbone=False)),
                                     ("context_norm_batch", dict(context_norm="batch"))])
 def test_state_dict_keys_match_reference(key_shapes, tag, kw):
