@@ -10,8 +10,9 @@ sequence per rank (no data-path collective; one all_gather of EPE statistics at 
     python bench.py --gpus N --steps K --warmup W          (N > 1 without a torchrun environment: spawns N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 with `roofline` (corr lookup, device-clock stamps in the timed region) and
-`cpu_baseline` (the CPU oracle on the host cores, rank 0 / N=1 only).
+Prints ONE JSON line on rank 0 with `roofline` (corr lookup: device-clock stamps of the frame's own launches, taken in a
+stamped pass after the timed region), `cpu_baseline` (the CPU oracle on the host cores, rank 0 / N=1 only) and `domain_flags`
+(the device-side NaN / saturation guard of the timed frames; non-zero = no headline, exit code 3).
 """
 import argparse
 import json
@@ -33,13 +34,9 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 LOOKUP_BYTES_PER_PIXEL = 308    # 4 levels x 10 taps x 4 B + 4 B coord + 36 x 4 B out
 
 
-def _contraction():
-    m = os.environ.get("TCS_MI355_MATH", "f16x3")
-    return ("fp16 hi/lo split operands, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate (error <= fp32 MFMA chain; "
-            "tests/test_gpu_parity.py::test_f16x3_split_is_fp32_grade)") if m == "f16x3" else "fp32 MFMA (v_mfma_f32_32x32x2_f32)"
-
-
-CONTRACTION = _contraction()
+CONTRACTION = ("convolutions: fp16 hi/lo split operands, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate (error <= fp32 MFMA "
+               "chain; tests/test_gpu_parity.py::test_f16x3_split_is_fp32_grade), loop and frame layers alike; the gradient-candidate stem "
+               "and the correlation volume: fp32 MFMA (v_mfma_f32_32x32x2_f32); everything else fp32 VALU")
 
 
 def log(msg):
@@ -153,35 +150,35 @@ def lookup_burst_us(dev, B, n=200, reps=5):
 
 
 def lookup_roofline(probe, snapshots, burst, pixels):
-    """`roofline` object for the corr lookup.  `achieved` / `frac` use the HIP-event duration (`lookup_burst_us`), which is
-    the launch-to-launch interval a stream of dependent kernels really pays and agrees with rocprofv3's kernel trace.
-    The in-kernel device-clock interval (first instruction of the first workgroup to the last acknowledged store of the
-    last one, s_memrealtime at 100 MHz, every lookup launch of the timed region) is reported next to it: the difference
-    is dispatch/completion overhead, not data movement."""
+    """`roofline` object for the corr lookup.  `achieved` / `frac` / `avg_launch_us` are the kernel's launches INSIDE the frame:
+    the in-kernel device-clock interval (first instruction of the first workgroup to the last acknowledged store of the last one,
+    s_memrealtime at 100 MHz) of every lookup launch of a stamped pass over the clip — the same graph as the timed frames plus the
+    stamps.  That is the figure rocprofv3's kernel trace of this command reproduces (`rocprof_loop_avg_us`, `frac_rocprof`, from
+    the committed profile; rocprofv3's interval adds its dispatch / completion overhead).  The isolated, cache-hot figures —
+    HIP events around graph-replayed bursts of 200 launches, and the stamps of those burst launches — are reported beside it as
+    `burst_events` and `in_kernel_hot`: they say what the kernel does alone, not what the frame gets."""
     burst_us, hot_us = burst
     durs = []
     for snap in snapshots:
         durs += probe.durations_us(snap)
     alg_bytes = LOOKUP_BYTES_PER_PIXEL * pixels
-    achieved = alg_bytes / (burst_us * 1e-6) / 1e9
-    roof = {"bound": "hbm", "kernel": "k_corr_lookup<4>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_us": round(burst_us, 3),
+    rate = lambda us: round(alg_bytes / (us * 1e-6) / 1e9, 1)
+    frac = lambda us: round(alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+    dur_us = float(np.mean(durs)) if durs else float("nan")
+    roof = {"bound": "hbm", "kernel": "k_corr_lookup<4>", "achieved": rate(dur_us) if durs else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": frac(dur_us) if durs else None, "traffic": None, "avg_launch_us": round(dur_us, 3) if durs else None,
+            "min_launch_us": round(float(np.min(durs)), 3) if durs else None, "launches": len(durs),
             "algorithmic_bytes_per_launch": alg_bytes,
-            "timer": "HIP events around graph-replayed bursts of 200 back-to-back launches on the launch stream"}
-    if durs:
-        dur_us = float(np.mean(durs))
-        roof["in_kernel"] = {"avg_launch_us": round(dur_us, 3), "min_launch_us": round(float(np.min(durs)), 3), "launches": len(durs),
-                             "achieved": round(alg_bytes / (dur_us * 1e-6) / 1e9, 1),
-                             "frac": round(alg_bytes / (dur_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                             "timer": "in-kernel s_memrealtime stamps (100 MHz), every lookup launch of the timed region"}
+            "timer": "in-kernel s_memrealtime stamps (100 MHz) of every lookup launch of a stamped pass over the clip (frame graph replay)"}
+    roof["burst_events"] = {"avg_launch_us": round(burst_us, 3), "achieved": rate(burst_us), "frac": frac(burst_us),
+                            "timer": "HIP events around graph-replayed bursts of 200 back-to-back launches, kernel alone, caches hot"}
     if hot_us:
-        roof["in_kernel_hot"] = {"median_launch_us": round(hot_us, 3), "achieved": round(alg_bytes / (hot_us * 1e-6) / 1e9, 1),
-                                 "frac": round(alg_bytes / (hot_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+        roof["in_kernel_hot"] = {"median_launch_us": round(hot_us, 3), "achieved": rate(hot_us), "frac": frac(hot_us),
                                  "timer": "in-kernel stamps of the burst launches (pyramid and coordinates cache-hot)"}
     # PMC traffic and rocprofv3's own durations come from the committed profile of this same command (profiles/README.md):
     # bench.py cannot run the profiler on itself.  rocprofv3's per-kernel interval includes ~2 us of dispatch / completion
     # (trivial kernels read 4.5-5 us in the same trace), so frac_rocprof is a lower bound of the kernel's own rate.
-    for name in ("r02_lookup_pmc.json", "r01_lookup_pmc.json"):
+    for name in ("r03_lookup_pmc.json", "r02_lookup_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 pmc = json.load(f)
@@ -191,9 +188,10 @@ def lookup_roofline(probe, snapshots, burst, pixels):
                 for key in ("rocprof_burst_avg_us", "rocprof_loop_avg_us", "rocprof_kernel_trace_avg_us"):
                     if key in pmc:
                         roof[key] = pmc[key]
-                rp = pmc.get("rocprof_burst_avg_us") or pmc.get("rocprof_kernel_trace_avg_us")
+                rp = pmc.get("rocprof_loop_avg_us") or pmc.get("rocprof_burst_avg_us") or pmc.get("rocprof_kernel_trace_avg_us")
                 if rp:
-                    roof["frac_rocprof"] = round(alg_bytes / (rp * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                    roof["frac_rocprof"] = frac(rp)
+                    roof["frac_rocprof_source"] = f"profiles/{name}: rocprofv3 --kernel-trace average of the frame's own lookup launches"
                 break
         except (OSError, KeyError, ValueError):
             continue
@@ -270,6 +268,30 @@ def real_data_leg(a, dev):
         return {"status": "failed", "reason": f"{type(e).__name__}: {e}"}
 
 
+def count_gpus_sysfs(root="/sys/class/kfd/kfd/topology/nodes"):
+    """GPUs the kernel driver exposes, read from the KFD topology (nodes with simd_count > 0; CPUs have 0) — no HIP, no amdsmi, so the
+    launcher process stays GPU-free.  Honours ROCR/HIP_VISIBLE_DEVICES by taking the shorter list.  None when the topology is unreadable
+    (then nothing is checked here: a rank whose LOCAL_RANK has no device fails fast and takes the others down)."""
+    import glob
+    n = 0
+    files = glob.glob(os.path.join(root, "*", "properties"))
+    if not files:
+        return None
+    try:
+        for f in files:
+            with open(f) as fh:
+                for line in fh:
+                    k, _, v = line.partition(" ")
+                    if k == "simd_count" and int(v) > 0:
+                        n += 1
+    except (OSError, ValueError):
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if os.environ.get(var, "").strip():
+            n = min(n, len([t for t in os.environ[var].split(",") if t.strip()]))
+    return n
+
+
 def spawn_ranks(a, argv):
     """`python bench.py --gpus N` outside torchrun: start N fresh rank processes (one per GPU, RCCL over xGMI) BEFORE this
     process has made any GPU call, relay rank 0's JSON line, exit with the worst return code.  The parent never touches
@@ -277,9 +299,8 @@ def spawn_ranks(a, argv):
     import socket
     import subprocess
     if not a.dry_run:
-        import torch
-        have = torch.cuda.device_count()             # counting devices does not initialise HIP on this image
-        if have < a.gpus:
+        have = count_gpus_sysfs()                    # no HIP / amdsmi call in the parent: it only starts the ranks
+        if have is not None and have < a.gpus:
             raise SystemExit(f"bench.py --gpus {a.gpus}: this box exposes {have} GPU(s); one rank per GPU is the only supported layout")
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
@@ -383,48 +404,81 @@ def main():
     seq = seqs[0]
     runner = ClipRunner(model, seqs, dev, ITERS)
 
-    from tcs_mi355 import ops
-    probe = ops.LookupProbe(dev, slots=64)
-    ops.LOOKUP_PROBE = probe             # before the first forward: the stamp slots are baked into the captured graphs
-    snaps = []
+    from tcs_mi355 import ops, s16
     with torch.no_grad():
         log("warm-up (captures the HIP graphs)")
         for _ in range(max(a.warmup, 2)):          # >= 2 so that both branches (first frame / temporal) are captured
             runner.step()
+        s16.take_flags()                           # clear: the flags below are those of the timed frames (synchronises)
         log(f"timing {a.steps} steps")
-        probe.reset()
-        torch.cuda.synchronize()
         tdist.barrier()
         t0 = time.perf_counter()
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
         for i in range(a.steps):
             marks[i].record()                      # per-step spread (diagnostic): events only, no host sync inside the region
-            runner.step()
-            snaps.append(probe.buf.clone())        # stream-ordered 300 KB copy + clear; no host sync
-            probe.reset()
+            runner.step()                          # the production graph: no stamps, no copies
         marks[-1].record()
         torch.cuda.synchronize()
         tdist.barrier()
         elapsed = time.perf_counter() - t0
         per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
-    ops.LOOKUP_PROBE = None
+    # the device-side replacement of the reference's NaN asserts (update.py:27-35,58-67,78-86,155-158): a timed frame whose
+    # activations left the S16 domain (bit 0: clamped at 65504, bit 1: NaN / Inf) was timed on garbage — no headline for it
+    domain_flags = s16.take_flags()
     graphs = getattr(model, "_graphs", None)
     if not a.eager and (graphs is None or graphs.fell_back or any(v is None for v in graphs.cache.values())):
         raise SystemExit("bench.py: a frame ran with eager launches although HIP-graph replay was requested "
                          f"(fell_back={getattr(graphs, 'fell_back', None)}); refusing to report it as graph replay")
+    # per-rank evaluation statistics of the same clip against the synthetic ground truth, through the harness: the vector every
+    # rank contributes to the run's one collective (evaluate_stereo.py:202-220; BASELINE configs[3]'s "RCCL EPE gather")
+    from tcs_mi355.harness import reduce_stats, run_sequence
+    with torch.no_grad():
+        eval_stats = run_sequence(model, seq, iters=ITERS, device=dev)
+    domain_flags |= eval_stats.domain_flags
+
+    # roofline pass: the same clip with the lookup's device-clock stamps on (graphs re-captured with the stamp slots baked in)
+    roof = None
     with torch.no_grad():
         try:
+            if rank != 0:
+                raise StopIteration                # the roofline object is rank 0's
+            probe = ops.LookupProbe(dev, slots=64)
+            ops.LOOKUP_PROBE = probe
+            model._graphs = None
+            runner_r = ClipRunner(model, seqs, dev, ITERS)
+            snaps = []
+            for _ in range(2):
+                runner_r.step()
+            probe.reset()
+            for _ in range(CLIP_LEN):
+                runner_r.step()
+                snaps.append(probe.buf.clone())    # stream-ordered 300 KB copy + clear; no host sync
+                probe.reset()
+            torch.cuda.synchronize()
+            ops.LOOKUP_PROBE = None
+            model._graphs = None                   # later legs capture without stamps again
             roof = lookup_roofline(probe, snaps, lookup_burst_us(dev, S), S * _quarter(HEIGHT) * _quarter(WIDTH))
+        except StopIteration:
+            pass
         except Exception as e:                    # never lose the headline line over the auxiliary timing
             log(f"lookup roofline timing failed: {type(e).__name__}: {e}")
-            roof = None
+        finally:
+            ops.LOOKUP_PROBE = None
 
     # the run's only collective (besides the two barriers): per-rank [pairs, elapsed]; the MAX over ranks of the elapsed
     # time and the aggregate come from it (EPE statistics ride the same vector in evaluation runs)
-    vecs = tdist.gather_vectors(np.array([a.steps * S, elapsed], np.float64))
+    vecs = tdist.gather_vectors(np.concatenate([np.array([a.steps * S, elapsed, float(domain_flags)], np.float64), eval_stats.vector()]))
     elapsed = max(float(v[1]) for v in vecs)
     total_pairs = sum(int(v[0]) for v in vecs)
     value = total_pairs / elapsed
+    all_flags = 0
+    for v in vecs:
+        all_flags |= int(v[2])
+    gathered_eval = reduce_stats([v[3:] for v in vecs])
+    if all_flags:
+        log(f"S16 domain flags {all_flags:#x} on the timed frames (bit 0: an activation was clamped at 65504, bit 1: NaN / Inf): the "
+            f"frames were timed on saturated tensors; refusing to print a headline")
+        raise SystemExit(3)
 
     # accuracy of the synthetic run (random-init weights: parity, not quality, is what is checked)
     gpu_preds = None
@@ -453,27 +507,36 @@ def main():
           seqs_b = [seq] + [synth.make_sequence(2000 + j, n_frames=CLIP_LEN, height=HEIGHT, width=WIDTH, max_disp=MAX_DISP)
                             for j in range(1, Sb)]
           runner_b = ClipRunner(model, seqs_b, dev, ITERS)
-          ops.LOOKUP_PROBE = probe_b = ops.LookupProbe(dev, slots=64)
-          snaps_b = []
           with torch.no_grad():
               for _ in range(2):
                   runner_b.step()
-              probe_b.reset()
               torch.cuda.synchronize()
               tb = time.perf_counter()
               for _ in range(a.steps):
                   runner_b.step()
+              torch.cuda.synchronize()
+              tb = time.perf_counter() - tb
+              flags_b = s16.take_flags()
+              # stamped pass for the lookup's in-frame duration at this batch size
+              ops.LOOKUP_PROBE = probe_b = ops.LookupProbe(dev, slots=64)
+              model._graphs = None
+              runner_s = ClipRunner(model, seqs_b, dev, ITERS)
+              snaps_b = []
+              for _ in range(2):
+                  runner_s.step()
+              probe_b.reset()
+              for _ in range(CLIP_LEN):
+                  runner_s.step()
                   snaps_b.append(probe_b.buf.clone())
                   probe_b.reset()
               torch.cuda.synchronize()
-              tb = time.perf_counter() - tb
-          ops.LOOKUP_PROBE = None
-          with torch.no_grad():
+              ops.LOOKUP_PROBE = None
+              model._graphs = None
               roof_b = lookup_roofline(probe_b, snaps_b, lookup_burst_us(dev, Sb), Sb * _quarter(HEIGHT) * _quarter(WIDTH))
           batched = {"seqs_per_gpu": Sb, "value": round(a.steps * Sb / tb, 4), "unit": "stereo-pairs/s",
-                     "ms_per_step": round(1e3 * tb / a.steps, 3),
-                     "lookup": {k: roof_b[k] for k in ("achieved", "frac", "avg_launch_us", "algorithmic_bytes_per_launch", "in_kernel")}}
-          del runner_b
+                     "ms_per_step": round(1e3 * tb / a.steps, 3), "domain_flags": flags_b,
+                     "lookup": {k: roof_b[k] for k in ("achieved", "frac", "avg_launch_us", "algorithmic_bytes_per_launch", "burst_events")}}
+          del runner_b, runner_s
       except Exception as e:                      # the extra leg must never cost the headline line
         log(f"batched leg failed: {type(e).__name__}: {e}")
         batched = {"seqs_per_gpu": a.batched_leg, "error": f"{type(e).__name__}: {e}"}
@@ -497,6 +560,8 @@ def main():
                                    + ("one sequence per GPU" if S == 1 else f"{S} independent sequences batched per GPU"),
                        "frames_per_rank": a.steps * S, "seqs_per_gpu": S, "weights": "key-seeded synthetic (tcs_mi355.weights)",
                        "launch": "eager" if a.eager else "hip-graph replay"},
+            "domain_flags": all_flags,
+            "gathered_eval_vs_synthetic_gt": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in gathered_eval.items()},
             "roofline": roof, "cpu_baseline": cpu, "epe_vs_oracle_first_frames": epe_vs_oracle, "batched_leg": batched,
             "tartanair_leg": real,
             "ranks_frames": [int(v[0]) for v in vecs],

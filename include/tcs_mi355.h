@@ -359,6 +359,13 @@ typedef struct tcs_conv_s16_desc {
      * out16_split must be a multiple of 32; NULL = single output. */
     void* out16b;
     int out16b_groups, out16_split;
+    /* DECONV2X: InstanceNorm2d statistics of the output computed by the transposed convolution itself (the up-blocks are
+     * ConvTranspose2d -> InstanceNorm2d -> LeakyReLU, core/utils/basic_layers.py:28-35,57): every workgroup leaves (mean, M2)
+     * of its tile per channel, the last one to finish (a ticket counter; nobody waits) merges them into (mean, 1/sqrt(var + in_eps))
+     * per (b, channel), read by tcs_instance_norm_apply_s16.  in_stats: tcs_deconv_in_stats_bytes() bytes, ZERO-FILLED once by the
+     * caller before the first use (it holds the counters; every launch re-arms them); needs Cout/4 % 32 == 0 and B <= 16.  NULL = off. */
+    float* in_stats;
+    float in_eps;
 } tcs_conv_s16_desc;
 
 /* S16 glue of the loop: pool2x / interp (core/update.py:114-124), the up-blocks' InstanceNorm + LeakyReLU + skip
@@ -370,6 +377,11 @@ int tcs_resize_bilinear_s16(const void* x, int B, int groups, int H, int W, int 
 size_t tcs_instance_norm_s16_workspace_bytes(int B, int groups, int H, int W);
 int tcs_instance_norm_s16(const void* x, int B, int groups, int H, int W, float eps, int act, const void* addend, int addend_groups,
                           void* out, int out_groups, void* workspace, tcs_stream_t stream);
+/* The apply half of tcs_instance_norm_s16 for statistics already computed by the producing transposed convolution
+ * (tcs_conv_s16_desc.in_stats; C = its Cout/4 channels, [H,W] = its OUTPUT grid): out = act((x - mean) * rstd) + addend. */
+size_t tcs_deconv_in_stats_bytes(int B, int C, int H_in, int W_in);
+int tcs_instance_norm_apply_s16(const void* x, int B, int groups, int H, int W, int act, const void* addend, int addend_groups,
+                                void* out, int out_groups, const float* in_stats, int C, tcs_stream_t stream);
 int tcs_propagate_disparity_s16(const float* grad, const float* disp, int B, int H, int W, float* cand9, void* out16, int out_groups,
                                 tcs_stream_t stream);
 int tcs_s16_set_channel(const float* x, int B, int H, int W, void* s16, int groups_total, int channel, tcs_stream_t stream);

@@ -28,16 +28,17 @@ from tcs_mi355.streams import fork_join
 # packed-weight cache: one device-side repack per conv, redone only if the parameter changes
 # ---------------------------------------------------------------------------------------------
 # Contraction arithmetic of tcs_conv2d: "f16x3" = fp16 hi/lo split on the half-precision matrix pipe with fp32
-# accumulation (fp32-equivalent accuracy, ~5x the fp32 MFMA rate), "f32" = fp32-in/fp32-out MFMA.  A layer can pin
-# its own mode with `conv._tcs_math`.
-CONV_MATH = os.environ.get("TCS_MI355_MATH", "f16x3")
+# accumulation (fp32-equivalent accuracy, ~5x the fp32 MFMA rate; the loop's S16 kernels exist in this form only),
+# "f32" = fp32-in/fp32-out MFMA.  A layer pins "f32" with `conv._tcs_math` (the gradient-candidate stem does: its inputs are
+# unbounded).  There is no global switch: a frame whose loop is fp16-split while its head is not would be neither.
+CONV_MATH = "f16x3"
 
 
 def packed(conv: nn.Conv2d) -> ops.PackedConv:
     w, b = conv.weight, conv.bias
     math = getattr(conv, "_tcs_math", None) or CONV_MATH
     if conv.stride == (2, 2):
-        math = "f16x3"          # stride-2 convolutions exist on the fp16-split kernel only (also under TCS_MI355_MATH=f32)
+        math = "f16x3"          # stride-2 convolutions exist on the fp16-split kernel only
     key = (w.data_ptr(), w._version, w.device, None if b is None else (b.data_ptr(), b._version), math)
     hit = getattr(conv, "_tcs_packed", None)
     if hit is None or hit[0] != key:
@@ -50,8 +51,8 @@ def packed(conv: nn.Conv2d) -> ops.PackedConv:
 
 
 def packed16(conv: nn.Conv2d) -> ops.PackedConv:
-    """fp16-split packing whatever TCS_MI355_MATH says: the S16 kernels contract fp16 halves by construction."""
-    if getattr(conv, "_tcs_math", None) == "f32" or CONV_MATH != "f16x3":
+    """fp16-split packing also for a layer pinned to fp32 MFMA on its fp32-tensor path: the S16 kernels contract fp16 halves by construction."""
+    if getattr(conv, "_tcs_math", None) == "f32":
         w, b = conv.weight, conv.bias
         key = (w.data_ptr(), w._version, w.device, None if b is None else (b.data_ptr(), b._version))
         hit = getattr(conv, "_tcs_packed16", None)
@@ -143,12 +144,20 @@ def up_block16(pool, block: Conv2x_IN, x: s16.S16, rem: s16.S16) -> s16.S16:
     """Conv2x_IN(deconv=True, concat=False) on S16 tensors: transposed conv -> InstanceNorm -> LeakyReLU -> + rem ->
     3x3 conv [-> InstanceNorm] -> LeakyReLU (basic_layers.py:38-77)."""
     dc = block.conv1.conv
-    y = s16.deconv4x4s2(packed_deconv(dc), [x], out16=pool.get((id(dc), "o"), x.B, dc.out_channels, 2 * x.H, 2 * x.W, x.device))
+    y = pool.get((id(dc), "o"), x.B, dc.out_channels, 2 * x.H, 2 * x.W, x.device)
+    stats = None
+    if "noinfuse" not in _X and s16.deconv_in_stats_ok(x.B, dc.out_channels):
+        # the transposed convolution reduces the InstanceNorm statistics of its own output (last-workgroup merge): no statistics
+        # launch between it and the apply kernel
+        stats = pool.get32((id(dc), "in_stats"), (s16.nv.lib().tcs_deconv_in_stats_bytes(x.B, dc.out_channels, x.H, x.W) // 4,), x.device,
+                           zero=True)
+    s16.deconv4x4s2(packed_deconv(dc), [x], out16=y, in_stats=stats)
+    norm = (lambda **kw: s16.instance_norm_apply(y, stats, **kw)) if stats is not None else (lambda **kw: s16.instance_norm(y, **kw))
     if (y.H, y.W) != (rem.H, rem.W):         # odd-sized skip: nearest resize as the reference does (rare; through fp32)
-        y32 = F.interpolate(s16.instance_norm(y, act="leaky", out=y).float(), size=(rem.H, rem.W), mode="nearest") + rem.float()
+        y32 = F.interpolate(norm(act="leaky", out=y).float(), size=(rem.H, rem.W), mode="nearest") + rem.float()
         y = to16(pool, y32, (id(dc), "resized"))
     else:
-        y = s16.instance_norm(y, act="leaky", addend=rem, out=y)
+        y = norm(act="leaky", addend=rem, out=y)
     act2 = "leaky" if block.conv2.relu else "none"
     if block.conv2.use_in:
         z = conv16(pool, block.conv2.conv, [y])

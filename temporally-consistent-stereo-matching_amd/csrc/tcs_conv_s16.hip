@@ -63,6 +63,8 @@ struct S16Args {
     const float* bl_cand; int bl_cand_ctot; const float* bl_disp;
     float* bl_refined; float* bl_delta; float* bl_coords1; float* bl_flow; _Float16* bl_f16; int bl_f16_groups, bl_f16_ch;
     _Float16* out16b; int out16b_groups, out16_split;   // LINEAR: channels >= out16_split go to this second S16 tensor (tcs_mi355.h)
+    float* in_ws;                       // DECONV2X: InstanceNorm statistics of the output, see s16_deconv_stats() (nullable)
+    float in_eps;
     int ablate;                         // diagnostic builds only (-DTCS_S16_ABLATE, tools/conv_s16_ablate.py): bit 0 skip the
                                         // input DMA, bit 1 skip the weight DMA, bit 2 skip operand reads + MFMAs (timing only)
 };
@@ -243,6 +245,123 @@ __device__ __forceinline__ void s16_epilogue_tile(const S16Args& a, int b, int c
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// InstanceNorm statistics of a transposed convolution's output, computed by the convolution itself (TCS_EPI_DECONV2X with
+// tcs_conv_s16_desc.in_stats): the up-blocks of both U-Nets are ConvTranspose2d -> InstanceNorm2d -> LeakyReLU
+// (core/utils/basic_layers.py:28-35,57), and the statistics pass was a launch of its own on the iteration's serial chain.
+//   * every workgroup reduces its tile — ROWS x 32 pixels of the input grid x 32 output channels of ONE output parity, i.e.
+//     ROWS x 32 values of each of 32 real channels — to (mean, M2) per channel: two-pass inside a wave (sum -> mean -> squared
+//     deviations, as the reference's variance), Chan's pairwise merge across the waves, and writes them to its slot;
+//   * a ticket counter per batch element tells the LAST workgroup to finish; that one merges all slots (fixed order, so the
+//     result does not depend on who was last) into (mean, 1/sqrt(var + eps)) per channel and re-arms the counter.
+// No workgroup ever waits for another one.  The values are the STORED ones (hi + lo of the S16 split), which is what the
+// apply kernel normalises.  Workspace (floats): [0, 16): ticket counters (uint, one per batch element, B <= 16; zero before the
+// first launch), then finals [B][C][2], then slots [B][nct32][npatch][32][2].
+// ---------------------------------------------------------------------------------------------------------------------
+#define S16_IN_WS_HEAD 16
+template <int MT, int ROWS>
+__device__ __forceinline__ void s16_deconv_stats(const S16Args& a, int b, int ct, int patch, int py, int px, int wave, int lane,
+                                                 const f32x16* acc, float* lds /* >= (ROWS * 64 + 8) floats, free to use */) {
+    const int C = a.hidden, l31 = lane & 31, half = lane >> 5;
+    const bool valid = px < a.W && py < a.H;
+    const int ncol = min(32, a.W - (px - l31)), n_wave = py < a.H ? ncol : 0;       // wave-uniform: this row's valid pixels
+    const int nslot_b = a.nct32 * a.npatch;
+    float* finals = a.in_ws + S16_IN_WS_HEAD + (size_t)b * C * 2;
+    float* slots = a.in_ws + S16_IN_WS_HEAD + (size_t)a.B * C * 2 + (size_t)b * nslot_b * 64;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        float v[16], mean[16], m2[16];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            half2_t hi, lo;
+            const float t0 = apply_act(acc[m][r] * a.w_unscale, a.act), t1 = apply_act(acc[m][r + 1] * a.w_unscale, a.act);
+            float2_t x;
+            x[0] = __builtin_amdgcn_fmed3f(t0, -65504.f, 65504.f);
+            x[1] = __builtin_amdgcn_fmed3f(t1, -65504.f, 65504.f);
+            hi = __builtin_convertvector(x, half2_t);
+            const float2_t back = __builtin_convertvector(hi, float2_t);
+            lo = __builtin_convertvector(x - back, half2_t);
+            v[r] = valid ? (float)hi[0] + (float)lo[0] : 0.f;
+            v[r + 1] = valid ? (float)hi[1] + (float)lo[1] : 0.f;
+        }
+        const float inv_n = n_wave > 0 ? 1.0f / (float)n_wave : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float sum = v[r];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);          // over the 32 pixels of this lane half
+            mean[r] = sum * inv_n;
+            const float d = valid ? v[r] - mean[r] : 0.f;
+            float q = d * d;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+            m2[r] = q;
+        }
+        // wave partials -> LDS [wave][half][16 regs][2]; lanes 0 and 32 hold their half's 16 channels
+        __syncthreads();                                   // the stage buffers are free once every wave has left the K loop
+        if (l31 == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                lds[((wave * 2 + half) * 16 + r) * 2 + 0] = mean[r];
+                lds[((wave * 2 + half) * 16 + r) * 2 + 1] = m2[r];
+            }
+        }
+        __syncthreads();
+        if (wave == 0 && lane < 32) {                      // lane = (half, r): merge the ROWS waves in row order (Chan et al.)
+            const int y0 = py;                             // wave 0's row = the patch's first row
+            float n = 0.f, mu = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < ROWS; ++w) {
+                const float ni = (y0 + w < a.H) ? (float)ncol : 0.f;
+                if (ni > 0.f) {
+                    const float mi = lds[((w * 2 + (lane >> 4)) * 16 + (lane & 15)) * 2], qi = lds[((w * 2 + (lane >> 4)) * 16 + (lane & 15)) * 2 + 1];
+                    const float tot = n + ni, f = ni / tot, dlt = mi - mu;
+                    mu += dlt * f;
+                    q += qi + dlt * dlt * n * f;
+                    n = tot;
+                }
+            }
+            // channel of (half, r) inside the tile: 4*half + (r&3) + 8*(r>>2)
+            const int hh = lane >> 4, r = lane & 15, cin_tile = 4 * hh + (r & 3) + 8 * (r >> 2);
+            float* sl = slots + ((size_t)(ct * MT + m) * a.npatch + patch) * 64;
+            sl[cin_tile * 2 + 0] = mu;
+            sl[cin_tile * 2 + 1] = q;
+        }
+    }
+    // ---- ticket: the last workgroup of this batch element merges every slot ------------------------------------------------
+    __threadfence();
+    __syncthreads();
+    unsigned* counter = reinterpret_cast<unsigned*>(a.in_ws) + b;
+    if (threadIdx.x == 0) {
+        const unsigned total = (unsigned)(a.npatch * a.nct);
+        const unsigned old = atomicAdd(counter, 1u);
+        reinterpret_cast<unsigned*>(lds)[0] = (old == total - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (reinterpret_cast<unsigned*>(lds)[0] == 0u) return;
+    __threadfence();                                       // acquire: the other workgroups' slots
+    const int tiles_per_par = C / 32;                      // C % 32 == 0 is checked by the launcher when statistics are requested
+    for (int c = threadIdx.x; c < C; c += 64 * ROWS) {
+        float n = 0.f, mu = 0.f, q = 0.f;
+        for (int par = 0; par < 4; ++par) {
+            const int tile = par * tiles_per_par + (c >> 5);
+            const float* sl = slots + (size_t)tile * a.npatch * 64 + (c & 31) * 2;
+            for (int p = 0; p < a.npatch; ++p) {
+                const int yy = (p / a.npx) * ROWS, xx = (p % a.npx) * 32;
+                const float ni = (float)(min(ROWS, a.H - yy) * min(32, a.W - xx));
+                const float mi = __builtin_nontemporal_load(sl + (size_t)p * 64), qi = __builtin_nontemporal_load(sl + (size_t)p * 64 + 1);
+                const float tot = n + ni, f = ni / tot, dlt = mi - mu;
+                mu += dlt * f;
+                q += qi + dlt * dlt * n * f;
+                n = tot;
+            }
+        }
+        finals[c * 2 + 0] = mu;
+        finals[c * 2 + 1] = 1.0f / sqrtf(q / n + a.in_eps);
+    }
+    if (threadIdx.x == 0) *counter = 0u;                   // re-armed for the next launch (stream order: nobody else is running)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -454,6 +573,12 @@ __global__ __launch_bounds__(64 * ROWS) void k_conv_s16(S16Args a) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) s16_epilogue_tile<EPI>(a, b, (ct * MT + m) * 32 + 4 * half, py, px, acc[m]);
     }
+    if constexpr (EPI == TCS_EPI_DECONV2X) {
+        if (a.in_ws) {
+            extern __shared__ __attribute__((aligned(16))) float s16_dyn_lds[];
+            s16_deconv_stats<MT, ROWS>(a, b, ct, patch, py, px, wave, lane, acc, s16_dyn_lds);
+        }
+    }
 #ifdef TCS_S16_ABLATE
     __builtin_amdgcn_s_waitcnt(0);                                  // stores acknowledged
     S16_STAMP(3)
@@ -597,6 +722,13 @@ static int s16_heuristic(const S16Args& a, int ksize, int stride, int kst1x1) {
 
 extern "C" {
 
+size_t tcs_deconv_in_stats_bytes(int B, int C, int H, int W) {
+    if (B <= 0 || B > S16_IN_WS_HEAD || C <= 0 || C % 32 != 0 || H <= 0 || W <= 0) return 0;
+    // the smallest patch any tile configuration uses is 4 rows x 32 columns of the INPUT grid
+    const size_t npatch = (size_t)tcs_cdiv(W, 32) * tcs_cdiv(H, 4), nct32 = (size_t)4 * C / 32;
+    return (S16_IN_WS_HEAD + (size_t)B * C * 2 + (size_t)B * nct32 * npatch * 64) * sizeof(float);
+}
+
 size_t tcs_s16_bytes(int B, int C, int H, int W) {
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
     const size_t G = (size_t)((C + 15) / 16) * 2;
@@ -665,6 +797,8 @@ int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
         if (d->epilogue != TCS_EPI_LINEAR || !a.out16 || a.out16_split <= 0 || a.out16_split % 32 != 0 || a.out16_split >= d->Cout) return TCS_EINVAL;
         if (a.out16b_groups < (d->Cout - a.out16_split + 7) / 8) return TCS_EINVAL;
     }
+    a.in_ws = d->in_stats; a.in_eps = d->in_eps;
+    if (a.in_ws && (d->epilogue != TCS_EPI_DECONV2X || d->Cout % 128 != 0 || d->B > S16_IN_WS_HEAD || !(d->in_eps >= 0.f))) return TCS_EINVAL;
     a.npx = 0; a.nct = 0; a.npatch = 0;
     a.csplit = (d->tile_cfg / 100000) % 10;            // 0 = cout tile fastest (one weight slice per XCD)
     a.ablate = d->tile_cfg / 1000000;                  // honoured by -DTCS_S16_ABLATE builds only

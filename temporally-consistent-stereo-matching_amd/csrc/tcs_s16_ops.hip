@@ -180,6 +180,33 @@ __global__ __launch_bounds__(INS_T) void k_in_apply_s16(const _Float16* __restri
     s16_store8(out + (((size_t)b * Go + g) * 2) * plane + u, plane, v);
 }
 
+// the apply half for statistics that the producing transposed convolution already reduced (tcs_conv_s16.hip: s16_deconv_stats):
+// finals = [B][C][2] (mean, 1/sqrt(var + eps)); one thread per unit, no merge loop
+__global__ __launch_bounds__(INS_T) void k_in_apply_final_s16(const _Float16* __restrict__ x, int Gt, int G, int H, int W, int C,
+                                                               const float* __restrict__ finals, int act,
+                                                               const _Float16* __restrict__ addend, int Ga, _Float16* __restrict__ out, int Go) {
+    const int b = blockIdx.y / G, g = blockIdx.y - b * G, bg = b * Gt + g;      // G = C/8 real groups of a tensor with Gt groups
+    const int HW = H * W, Wp = W + 2;
+    const size_t plane = (size_t)(H + 2) * Wp * 8;
+    const int p = blockIdx.x * INS_T + threadIdx.x;
+    if (p >= HW) return;
+    const int y = p / W, xx = p - y * W;
+    const size_t u = ((size_t)(y + 1) * Wp + xx + 1) * 8;
+    float v[8], t[8];
+    s16_load8(x + ((size_t)bg * 2) * plane + u, plane, v);
+    if (addend) s16_load8(addend + (((size_t)b * Ga + g) * 2) * plane + u, plane, t);
+    const float4* f = reinterpret_cast<const float4*>(finals + ((size_t)b * C + min(g * 8, C - 8)) * 2);      // wave-uniform
+    const float4 f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
+    const float mean[8] = {f0.x, f0.z, f1.x, f1.z, f2.x, f2.z, f3.x, f3.z}, rstd[8] = {f0.y, f0.w, f1.y, f1.w, f2.y, f2.w, f3.y, f3.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const bool real = g * 8 + j < C;                   // padding channels of the last group stay zero
+        v[j] = real ? s16_act((v[j] - mean[j]) * rstd[j], act) + (addend ? t[j] : 0.f) : 0.f;
+        if (act == TCS_ACT_RELU_ADD_RELU) v[j] = fmaxf(v[j], 0.f);
+    }
+    s16_store8(out + (((size_t)b * Go + g) * 2) * plane + u, plane, v);
+}
+
 // update.py:259-289 with the stem's input laid out for tcs_conv2d_s16: out16 = S16 [B][4 groups][...] holding the 27
 // channels cat(candidates(9), |g_c - g_n| x (9), |g_c - g_n| y (9)) (+5 zero channels), cand9 = the 9 candidates as
 // fp32 NCHW for the blend kernel.
@@ -275,6 +302,19 @@ int tcs_instance_norm_s16(const void* x, int B, int groups, int H, int W, float 
     hipLaunchKernelGGL(k_in_apply_s16, dim3(tcs_cdiv(HW, INS_T), B * groups), dim3(INS_T), 0, s, reinterpret_cast<const _Float16*>(x), groups, H, W,
                        slice, nsl, reinterpret_cast<const float*>(workspace), eps, act, reinterpret_cast<const _Float16*>(addend), addend_groups,
                        reinterpret_cast<_Float16*>(out), out_groups);
+    return tcs_launch_status();
+}
+
+int tcs_instance_norm_apply_s16(const void* x, int B, int groups, int H, int W, int act, const void* addend, int addend_groups,
+                                void* out, int out_groups, const float* in_stats, int C, tcs_stream_t stream) {
+    if (!x || !out || !in_stats || B <= 0 || B > 16 || groups <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 32 != 0 || groups * 8 < C) return TCS_EINVAL;
+    if (act != TCS_ACT_NONE && act != TCS_ACT_RELU && act != TCS_ACT_LEAKY && act != TCS_ACT_RELU_ADD_RELU) return TCS_EUNSUPPORTED;
+    if (act == TCS_ACT_RELU_ADD_RELU && !addend) return TCS_EINVAL;
+    if (out_groups != groups || (addend && addend_groups != groups)) return TCS_EUNSUPPORTED;
+    const int G = C / 8;                                   // real groups (C % 32 == 0: no partial group)
+    hipLaunchKernelGGL(k_in_apply_final_s16, dim3(tcs_cdiv((long long)H * W, INS_T), B * G), dim3(INS_T), 0, tcs_stream(stream),
+                       reinterpret_cast<const _Float16*>(x), groups, G, H, W, C, in_stats + 16 /* S16_IN_WS_HEAD */, act,
+                       reinterpret_cast<const _Float16*>(addend), addend_groups, reinterpret_cast<_Float16*>(out), out_groups);
     return tcs_launch_status();
 }
 
@@ -392,7 +432,11 @@ __device__ __forceinline__ float hu_rcp(float d) {
     const float r = __builtin_amdgcn_rcpf(d);
     return fmaf(fmaf(-d, r, 1.0f), r, r);
 }
-__device__ __forceinline__ float hu_sigmoid(float v) { return hu_rcp(1.0f + hu_exp(-v)); }
+// The argument is clamped to +-30 first: beyond |v| ~ 88.7 exp2 overflows to Inf, the correction term turns Inf into NaN (Inf - Inf) and
+// v_rcp's Newton step does the same (-Inf * 0) — where torch.sigmoid (core/update.py:62-63) just saturates.  sigmoid(-30) = 9.4e-14:
+// the clamp changes no result by more than that.  Found on BASELINE configs[1]: frame 9, iteration 30 of one free run, a 6-px jump
+// of the refined disparity -> gate pre-activations beyond -88.7 -> NaN stored as 65504 into net08 (tools/flag_bisect.py).
+__device__ __forceinline__ float hu_sigmoid(float v) { return hu_rcp(1.0f + hu_exp(-__builtin_amdgcn_fmed3f(v, -30.f, 30.f))); }
 __device__ __forceinline__ float hu_tanh(float v) {
     const float e = hu_exp(2.0f * fminf(fmaxf(v, -15.f), 15.f));
     return 1.0f - 2.0f * hu_rcp(e + 1.0f);

@@ -55,6 +55,7 @@ class ConvS16Desc(C.Structure):
         ("blend_cand", c_fp), ("blend_cand_ctot", c_int), ("blend_disp", c_fp), ("blend_refined", c_fp), ("blend_delta", c_fp),
         ("blend_coords1", c_fp), ("blend_flow_x", c_fp), ("blend_flow16", c_fp), ("blend_flow16_groups", c_int), ("blend_flow16_channel", c_int),
         ("out16b", c_fp), ("out16b_groups", c_int), ("out16_split", c_int),
+        ("in_stats", c_fp), ("in_eps", c_f),
     ]
 
 
@@ -106,6 +107,8 @@ SIGNATURES = {
     "tcs_resize_bilinear_s16": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_int, c_fp]),
     "tcs_instance_norm_s16_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
     "tcs_instance_norm_s16": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_f, c_int, c_fp, c_int, c_fp, c_int, c_fp, c_fp]),
+    "tcs_deconv_in_stats_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
+    "tcs_instance_norm_apply_s16": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_int, c_fp, c_int, c_fp, c_int, c_fp]),
     "tcs_propagate_disparity_s16": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_int, c_fp]),
     "tcs_s16_set_channel": (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_int, c_int, c_fp]),
     "tcs_weight_frags_bytes": (c_sz, [c_int, c_int]),

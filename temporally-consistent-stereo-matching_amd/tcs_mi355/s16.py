@@ -82,13 +82,14 @@ class S16Pool:
             self.buffers[k] = buf
         return buf
 
-    def get32(self, key, shape, device) -> torch.Tensor:
+    def get32(self, key, shape, device, zero: bool = False) -> torch.Tensor:
         """A persistent fp32 scratch tensor (e.g. a GRU's update gate).  Like the S16 buffers it is never freed while the
-        model lives: captured HIP graphs hold raw pointers to it, and a freed block could be handed to another tensor."""
+        model lives: captured HIP graphs hold raw pointers to it, and a freed block could be handed to another tensor.
+        `zero`: zero-filled at allocation (ticket counters of the fused InstanceNorm statistics)."""
         k = (key, tuple(int(v) for v in shape), "f32", str(device))
         buf = self.buffers.get(k)
         if buf is None:
-            buf = self.buffers[k] = torch.empty(*k[1], dtype=torch.float32, device=device)
+            buf = self.buffers[k] = (torch.zeros if zero else torch.empty)(*k[1], dtype=torch.float32, device=device)
         return buf
 
     def bytes(self) -> int:
@@ -196,8 +197,24 @@ def conv2d(pc: PackedConv, srcs: Sequence[S16], act: str = "none", addend: Optio
     return out16, out32
 
 
-def deconv4x4s2(pc: PackedConv, srcs: Sequence[S16], out16: Optional[S16] = None, act: str = "none", tile_cfg: int = 0) -> S16:
-    """ConvTranspose2d(k=4, s=2, p=1, no bias) (+ activation): S16 [B,Cin,H,W] -> S16 [B,Cout,2H,2W]."""
+def deconv_in_stats_ok(B: int, cout: int) -> bool:
+    """Can the transposed convolution compute the InstanceNorm statistics of its own output (tcs_conv_s16_desc.in_stats)?"""
+    return cout % 32 == 0 and B <= 16
+
+
+def deconv_in_stats_workspace(B: int, cout: int, H: int, W: int, device) -> torch.Tensor:
+    """Zero-filled workspace for `deconv4x4s2(..., in_stats=)`: ticket counters, per-channel (mean, rstd), per-workgroup slots.
+    [H, W] is the transposed convolution's INPUT grid.  Allocate once and keep (the launches re-arm the counters)."""
+    n = nv.lib().tcs_deconv_in_stats_bytes(int(B), int(cout), int(H), int(W))
+    if n == 0:
+        raise ValueError("deconv_in_stats_workspace: needs cout % 32 == 0 and B <= 16")
+    return torch.zeros(n // 4, dtype=torch.float32, device=device)
+
+
+def deconv4x4s2(pc: PackedConv, srcs: Sequence[S16], out16: Optional[S16] = None, act: str = "none", tile_cfg: int = 0,
+                in_stats: Optional[torch.Tensor] = None, eps: float = 1e-5) -> S16:
+    """ConvTranspose2d(k=4, s=2, p=1, no bias) (+ activation): S16 [B,Cin,H,W] -> S16 [B,Cout,2H,2W].  With `in_stats`
+    (deconv_in_stats_workspace) the launch also leaves InstanceNorm2d's (mean, rstd) of its output there, for `instance_norm_apply`."""
     d = _desc(pc, srcs)
     cout = pc.cout // 4
     if out16 is None:
@@ -206,9 +223,26 @@ def deconv4x4s2(pc: PackedConv, srcs: Sequence[S16], out16: Optional[S16] = None
         raise ValueError("deconv4x4s2: bad `out16` grid")
     d.epilogue, d.act = EPI_DECONV2X, ACT[act]
     d.out16, d.out16_groups, d.out16_group_offset = out16.ptr(), out16.G, 0
+    if in_stats is not None:
+        if in_stats.numel() * 4 < nv.lib().tcs_deconv_in_stats_bytes(d.B, cout, d.H, d.W):
+            raise ValueError("deconv4x4s2: `in_stats` workspace too small for this layer")
+        d.in_stats, d.in_eps = nv.ptr(in_stats, "in_stats"), float(eps)
     d.tile_cfg = int(tile_cfg)
     nv.check(nv.lib().tcs_conv2d_s16(C.byref(d), nv.stream()), "tcs_conv2d_s16[deconv2x]")
     return out16
+
+
+def instance_norm_apply(x: S16, in_stats: torch.Tensor, act: str = "none", addend: Optional[S16] = None, out: Optional[S16] = None) -> S16:
+    """act((x - mean) * rstd) + addend with the statistics the producing `deconv4x4s2(..., in_stats=)` left behind; `out` may be `x`."""
+    out = zeros(x.B, x.C, x.H, x.W, x.device, x.G) if out is None else out
+    if addend is not None and (addend.B, addend.H, addend.W, addend.G) != (x.B, x.H, x.W, x.G):
+        raise ValueError("instance_norm_apply: bad addend")
+    if (out.B, out.H, out.W, out.G) != (x.B, x.H, x.W, x.G):
+        raise ValueError("instance_norm_apply: bad `out`")
+    nv.check(nv.lib().tcs_instance_norm_apply_s16(x.ptr(), x.B, x.G, x.H, x.W, ACT[act], None if addend is None else addend.ptr(),
+                                                  0 if addend is None else addend.G, out.ptr(), out.G, nv.ptr(in_stats, "in_stats"), x.C,
+                                                  nv.stream()), "tcs_instance_norm_apply_s16")
+    return out
 
 
 def gru_gates(pc_zr: PackedConv, srcs: Sequence[S16], h: S16, cz=None, cr=None, z_out: Optional[torch.Tensor] = None,

@@ -316,6 +316,43 @@ def test_hidden_update_fused_vs_torch(dev):
     assert float(d[:, :, :, 0].abs().max()) == 0 and float(d[:, :, :, :, -1].abs().max()) == 0        # border untouched
 
 
+def test_hidden_update_fused_saturating_gates(dev):
+    """Gate pre-activations far beyond +-88.7 (where exp overflows in fp32): torch.sigmoid (update.py:62-63) saturates at 0 / 1 and so must
+    the fused kernel's hardware exp / rcp path — it returned NaN there (stored as 65504 into net08, domain flag 0x2) until the
+    argument was clamped.  delta of +-100 and +-1000 px drives |pre| into the hundreds / thousands; every activation stays inside the
+    S16 domain, so the flag word must stay clean."""
+    from tcs_mi355 import s16
+    gen = torch.Generator().manual_seed(22)
+    B, H, W = 1, 8, 64
+    h = torch.tanh(torch.randn(B, 128, H, W, generator=gen))
+    delta = torch.randn(B, 1, H, W, generator=gen) * 2
+    delta[0, 0, 0, :] = 100.0
+    delta[0, 0, 1, :] = -100.0
+    delta[0, 0, 2, :] = 1000.0
+    delta[0, 0, 3, :] = -1000.0
+    w1, b1 = torch.randn(64, 1, 1, 1, generator=gen), torch.randn(64, generator=gen) * 0.1
+    w2, b2 = torch.randn(64, 64, 1, 1, generator=gen) * 0.15, torch.randn(64, generator=gen) * 0.1
+    wzr, bzr = torch.randn(256, 192, 1, 1, generator=gen) * 0.08, torch.randn(256, generator=gen) * 0.1
+    wq, bq = torch.randn(128, 192, 1, 1, generator=gen) * 0.08, torch.randn(128, generator=gen) * 0.1
+    x = F.conv2d(F.leaky_relu(F.conv2d(delta.double(), w1.double(), b1.double()), 0.01), w2.double(), b2.double())
+    pre = F.conv2d(torch.cat([h.double(), x], 1), wzr.double(), bzr.double())
+    assert float(pre.min()) < -200 and float(pre.max()) > 200 and float(x.abs().max()) < 6.0e4        # the case is what it claims to be
+    zr = torch.sigmoid(pre)
+    z, r = zr[:, :128], zr[:, 128:]
+    q = torch.tanh(F.conv2d(torch.cat([r * h, x], 1), wq.double(), bq.double()))
+    ref = z * h + (1 - z) * q
+    s16.take_flags()
+    h16 = s16.to_s16(D(h, dev))
+    s16.hidden_update(h16, D(delta, dev), D(w1.reshape(64), dev), D(b1, dev), s16.pack_frags(D(w2, dev), D(b2, dev), 64),
+                      s16.pack_frags(D(wzr, dev), D(bzr, dev), 128), s16.pack_frags(D(wq, dev), D(bq, dev), 0))
+    got = h16.float()
+    assert bool(torch.isfinite(got).all()) and float(got.abs().max()) <= 1.0 + 1e-6
+    # rows 0-3 carry pre-activations with ~1e-4 (delta = 100) / ~1e-3 (1000) of absolute fp32 rounding: their gates are saturated
+    # wherever that matters, so the result still agrees to 1e-5
+    assert maxdiff(got, ref) <= 1e-5
+    assert s16.take_flags() == 0
+
+
 def test_domain_guard_flags(dev):
     """The split's domain (|x| <= 65504, finite) is guarded by a device-side flag word instead of the reference's host-synchronising
     NaN asserts (update.py:27-35,...): saturation and non-finite values are reported, ordinary data is silent."""
@@ -359,3 +396,33 @@ def test_conv2d_s16_two_outputs_equal_separate_launches(dev):
             assert maxdiff(o.float(), torch.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1))) <= 2e-5
     with pytest.raises(RuntimeError):          # the split must be tile aligned
         s16.conv2d(pc, [x16], out16=oa, out16b=ob, out16_split=16)
+
+
+def test_deconv_fused_instance_norm_statistics(dev):
+    """tcs_conv_s16_desc.in_stats: the transposed convolution leaves InstanceNorm2d's (mean, rstd) of its own output (last-workgroup
+    merge), tcs_instance_norm_apply_s16 normalises with them (basic_layers.py:28-35,57).  Against fp64 on the CPU, against the
+    two-launch tcs_instance_norm_s16 on the same tensor, and repeatedly through one workspace (the ticket counter re-arms)."""
+    from tcs_mi355 import ops, s16
+    gen = torch.Generator().manual_seed(23)
+    # (cin, cout, H, W, B): the two up-blocks of the gradient predictor at 640x480, a ragged grid, batch 2
+    for cin, cout, H, W, B in ((128, 96, 30, 40, 1), (96, 64, 60, 80, 1), (64, 32, 7, 37, 2), (32, 64, 9, 33, 1)):
+        wt = torch.randn(cin, cout, 4, 4, generator=gen) * (1.0 / (cin * 4)) ** 0.5
+        x = torch.randn(B, cin, H, W, generator=gen) + 0.3
+        rem = torch.randn(B, cout, 2 * H, 2 * W, generator=gen)
+        y_ref = F.conv_transpose2d(x.double(), wt.double(), stride=2, padding=1)
+        ref = F.leaky_relu(F.instance_norm(y_ref, eps=1e-5), 0.01) + rem.double()
+        pc = ops.pack_deconv4x4s2(D(wt, dev))
+        x16, rem16 = s16.to_s16(D(x, dev)), s16.to_s16(D(rem, dev))
+        ws = s16.deconv_in_stats_workspace(B, cout, H, W, dev)
+        for rep in range(3):
+            for tc in (0, 1412, 101812):
+                y = s16.deconv4x4s2(pc, [x16], in_stats=ws, tile_cfg=tc)
+                fin = ws[16:16 + B * cout * 2].view(B, cout, 2).cpu().double()
+                ys = y.float().cpu().double()
+                assert maxdiff(fin[..., 0], ys.mean((2, 3))) <= 1e-5, (cout, tc)
+                assert float(((fin[..., 1] - 1 / torch.sqrt(ys.var((2, 3), unbiased=False) + 1e-5)).abs() * torch.sqrt(ys.var((2, 3), unbiased=False) + 1e-5)).max()) <= 1e-5
+                assert int(ws[:16].view(torch.int32).abs().max()) == 0                      # counters re-armed
+                two = s16.instance_norm(y, act="leaky", addend=rem16)                       # the two-launch reference path
+                got = s16.instance_norm_apply(y, ws, act="leaky", addend=rem16, out=y)
+                assert got is y and maxdiff(y.float(), two.float()) <= 2e-6, (cout, tc)
+                assert maxdiff(y.float(), ref) <= 3e-5, (cout, tc)

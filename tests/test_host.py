@@ -338,3 +338,19 @@ def test_formats_match_reference_fixtures(tmp_path):
     assert got.shape == g["sceneflow_pose_out"].shape and np.abs(got - g["sceneflow_pose_out"]).max() <= 1e-12
     img = harness._read_rgb(put("000000_left.png", "png_file"))
     assert img.dtype == np.float32 and np.array_equal(img, g["png_out"])
+
+
+def test_gpu_count_from_kfd_topology(tmp_path, monkeypatch):
+    """bench.py's launcher counts GPUs from the KFD topology in sysfs (no HIP / amdsmi call in the parent of the ranks)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for i, simd in enumerate((0, 0, 256, 256, 256)):                   # two CPU nodes, three GPUs
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {16 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.count_gpus_sysfs(str(tmp_path)) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.count_gpus_sysfs(str(tmp_path)) == 2
+    assert bench.count_gpus_sysfs(str(tmp_path / "missing")) is None
