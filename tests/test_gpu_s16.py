@@ -347,9 +347,11 @@ def test_hidden_update_fused_saturating_gates(dev):
                       s16.pack_frags(D(wzr, dev), D(bzr, dev), 128), s16.pack_frags(D(wq, dev), D(bq, dev), 0))
     got = h16.float()
     assert bool(torch.isfinite(got).all()) and float(got.abs().max()) <= 1.0 + 1e-6
-    # rows 0-3 carry pre-activations with ~1e-4 (delta = 100) / ~1e-3 (1000) of absolute fp32 rounding: their gates are saturated
-    # wherever that matters, so the result still agrees to 1e-5
-    assert maxdiff(got, ref) <= 1e-5
+    # rows 4.. are ordinary data: 1e-5.  Rows 0-3 carry pre-activations of 1e3 (delta = 100) / 1e4 (1000) whose fp32 rounding alone is
+    # ~1e-4 / ~1e-3 absolute (any fp32 implementation, the reference's included, has it): where a gate or q is not saturated the
+    # result moves by that much; the point of these rows is finite values and correct saturation
+    assert maxdiff(got[:, :, 4:], ref[:, :, 4:]) <= 1e-5
+    assert maxdiff(got[:, :, 0:2], ref[:, :, 0:2]) <= 2e-4 and maxdiff(got[:, :, 2:4], ref[:, :, 2:4]) <= 2e-3
     assert s16.take_flags() == 0
 
 
