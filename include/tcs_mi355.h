@@ -366,6 +366,14 @@ typedef struct tcs_conv_s16_desc {
      * caller before the first use (it holds the counters; every launch re-arms them); needs Cout/4 % 32 == 0 and B <= 16.  NULL = off. */
     float* in_stats;
     float in_eps;
+    /* LINEAR, stride 1: "tap partials" of a FOLLOWING 3x3 convolution to tap_nout = 1 or 2 channels (FlowHead.conv2, core/update.py:13-17;
+     * DispGradPredictor.residual_head[2], core/update.py:196,213), so that that convolution never runs as a launch: for each of the first
+     * tap_tiles 32-channel output tiles this launch also writes tap_out[b][tile][o*9 + t][H][W] = sum_{c in tile} w2[o][c][t] * out[c]
+     * (fp32), w2 packed by tcs_pack_tap_weights.  tcs_taps_sum / tcs_flow_taps_step_grads / tcs_taps_propagate_s16 finish the sum over
+     * tiles and taps.  With tap_out the S16 / fp32 outputs of those tiles are optional (out16 may be NULL). */
+    const float* tap_weights;
+    float* tap_out;
+    int tap_nout, tap_tiles;
 } tcs_conv_s16_desc;
 
 /* S16 glue of the loop: pool2x / interp (core/update.py:114-124), the up-blocks' InstanceNorm + LeakyReLU + skip
@@ -382,6 +390,19 @@ int tcs_instance_norm_s16(const void* x, int B, int groups, int H, int W, float 
 size_t tcs_deconv_in_stats_bytes(int B, int C, int H_in, int W_in);
 int tcs_instance_norm_apply_s16(const void* x, int B, int groups, int H, int W, int act, const void* addend, int addend_groups,
                                 void* out, int out_groups, const float* in_stats, int C, tcs_stream_t stream);
+/* Tap partials (tcs_conv_s16_desc.tap_*): weights [nout][C][3][3] -> the producer's order (tcs_tap_weights_floats floats);
+ * tcs_taps_sum: out[B,nout,H,W] = (addend + bias + sum over tiles and in-image taps) * scale (addend, bias nullable);
+ * tcs_flow_taps_step_grads = tcs_flow_step_grads with delta = bias[0] + taps (FlowHead's output, also written to delta_out when
+ * non-NULL); tcs_taps_propagate_s16 = tcs_propagate_disparity_s16 with grad = (g5 + bias2 + taps) * post_scale (core/update.py:213),
+ * also written to grad_out [B,2,H,W] when non-NULL. */
+size_t tcs_tap_weights_floats(int nout, int C);
+int tcs_pack_tap_weights(const float* w_oihw, int nout, int C, float* packed, tcs_stream_t stream);
+int tcs_taps_sum(const float* taps, int ntile, int nout, const float* bias, const float* addend, float scale, int B, int H, int W, float* out,
+                 tcs_stream_t stream);
+int tcs_flow_taps_step_grads(const float* coords1, const float* taps, int ntile, const float* bias, int B, int H, int W, float scale,
+                             float* disp_q, float* grad, float* cands, float* delta_out, tcs_stream_t stream);
+int tcs_taps_propagate_s16(const float* taps, int ntile, const float* bias2, const float* g5, float post_scale, const float* disp, int B, int H,
+                           int W, float* grad_out, float* cand9, void* out16, int out_groups, tcs_stream_t stream);
 int tcs_propagate_disparity_s16(const float* grad, const float* disp, int B, int H, int W, float* cand9, void* out16, int out_groups,
                                 tcs_stream_t stream);
 int tcs_s16_set_channel(const float* x, int B, int H, int W, void* s16, int groups_total, int channel, tcs_stream_t stream);

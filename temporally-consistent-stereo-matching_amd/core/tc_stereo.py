@@ -253,16 +253,21 @@ class TCStereo(nn.Module):
                     up32 = ub.run_gru32(pool, nets, inp_list)
                     return (up32, ub.gru16_early(pool, nets, inp_list, up32)) if "nog16split" not in _X else up32
                 early32 = spawn(ahead, site="gru32")
-            delta_flow = ub.run_fine(pool, nets, inp_list, m, up16)
+            sums = getattr(self, "_checksums", None)       # debugging hook (tools/determinism_check.py): device-side sums, no sync
+            lazy = trace is None and sums is None           # the hooks want the flow head's / residual head's outputs as tensors
+            delta_flow = ub.run_fine(pool, nets, inp_list, m, up16, lazy=lazy)
             # disp_q = x - (coords1 + delta), 5 * disp2disp_gradient_xy (update.py:199) and the gradient candidates in one
-            # launch; coords1 is replaced by the blend kernel's output below
-            disp_q, g5, cands = ops.flow_step_grads(coords1, delta_flow, scale=5.0)
-            disp_grad, context = self.disp_grad_refine.run(pool, g5, cands, dg_pre)
+            # launch (with the flow head's last convolution finished from its tap partials); coords1 is replaced by the blend
+            # kernel's output below
+            if isinstance(delta_flow, s16.Taps):
+                disp_q, g5, cands = s16.flow_taps_step_grads(coords1, delta_flow, scale=5.0)
+            else:
+                disp_q, g5, cands = ops.flow_step_grads(coords1, delta_flow, scale=5.0)
+            disp_grad, context = self.disp_grad_refine.run(pool, g5, cands, dg_pre, lazy=lazy)
             last = itr == iters - 1
             refined, up_mask, fused = self.disp_refine.run(pool, disp_grad, disp_q, nets[0], context, want_mask=last, motion=motion)
             hu_delta = fused["delta_disp"]
             coords1, flows_x = fused["coords1"], fused["flow_x"]
-            sums = getattr(self, "_checksums", None)       # debugging hook (tools/determinism_check.py): device-side sums, no sync
             if sums is not None:
                 sums.append({k: v.double().sum() for k, v in dict(
                     corr=corr, motion=m.data, net0=nets[0].data, net1=nets[1].data, net2=nets[2].data, delta_flow=delta_flow,

@@ -95,6 +95,28 @@ def packed16_cat(convs) -> ops.PackedConv:
     return hit[1]
 
 
+def tap_weights(conv2: nn.Conv2d) -> torch.Tensor:
+    w = conv2.weight
+    key = (w.data_ptr(), w._version, w.device)
+    hit = getattr(conv2, "_tcs_taps", None)
+    if hit is None or hit[0] != key:
+        hit = (key, s16.pack_taps(w))
+        conv2._tcs_taps = hit
+    return hit[1]
+
+
+def tap_partials(pool, conv1: nn.Conv2d, conv2: nn.Conv2d, srcs, pc=None, out16b=None) -> s16.Taps:
+    """relu(conv1(srcs)) with conv2 (3x3 to 1-2 channels) folded into its epilogue as tap partials.  `pc` / `out16b`: conv1 is the
+    leading channel range of a wider joint launch (packed16_cat) whose remaining channels go to `out16b`."""
+    a = srcs[0]
+    ntile = (conv1.out_channels + 31) // 32
+    taps = s16.Taps(pool.get32((id(conv2), "taps"), (a.B, ntile, 9 * conv2.out_channels, a.H, a.W), a.device), ntile, conv2.out_channels,
+                    None if conv2.bias is None else conv2.bias.detach())
+    s16.conv2d(packed16(conv1) if pc is None else pc, srcs, act="relu", taps=taps, tap_weights=tap_weights(conv2), out16b=out16b,
+               out16_split=conv1.out_channels if out16b is not None else 0)
+    return taps
+
+
 def pool_of(module) -> s16.S16Pool:
     """The S16 buffer pool of the model a module belongs to (TCStereo shares one; a stand-alone module gets its own)."""
     p = getattr(module, "_s16pool", None)
@@ -314,9 +336,13 @@ class FlowHead(nn.Module):
         self.conv2 = _conv(hidden_dim, output_dim, 3)
         self.relu = nn.ReLU(inplace=True)
 
-    def run(self, pool, x: s16.S16) -> torch.Tensor:
-        """-> fp32 [B,out,H,W].  The 256 -> 1 head runs on the S16 kernel too: one 32-wide tile of which one row is real costs
-        ~10 us, less than the fp32 reduction kernel it replaces (15.6 us), and needs no fp32 copy of the 256 channels."""
+    def run(self, pool, x: s16.S16, lazy: bool = False):
+        """-> fp32 [B,out,H,W], or with `lazy` the tap partials of conv2 (s16.Taps) for a consumer that finishes the sum itself.
+        conv2 (256 -> 1 or 2 channels, 3x3) never runs as a launch: conv1's epilogue leaves 9 partial sums per 32-channel tile and
+        output (csrc/tcs_stencil.hip, "Tap partials"), and the 256-channel intermediate is never stored."""
+        if self.conv2.out_channels <= 2 and "notaps" not in _X:
+            taps = tap_partials(pool, self.conv1, self.conv2, [x])
+            return taps if lazy else s16.taps_sum(taps)
         y = conv16(pool, self.conv1, [x], act="relu")
         return conv16(pool, self.conv2, [y], want32=True)
 
@@ -462,10 +488,11 @@ class BasicMultiUpdateBlock(nn.Module):
                                        out=pool.get((id(self), "up16"), net[0].B, net[1].C, net[0].H, net[0].W, net[0].device))
         return None
 
-    def run_fine(self, pool, net, inp, motion_features, up16, update=True):
-        """gru08 on (motion features, upsampled net16) and the flow head (update.py:154-168); returns delta_flow (fp32)."""
+    def run_fine(self, pool, net, inp, motion_features, up16, update=True, lazy=False):
+        """gru08 on (motion features, upsampled net16) and the flow head (update.py:154-168); returns delta_flow (fp32), or with
+        `lazy` the flow head's tap partials (FlowHead.run)."""
         self.gru08.step16(pool, net[0], [motion_features] + ([up16] if up16 is not None else []), *inp[0])
-        return self.flow_head.run(pool, net[0]) if update else None
+        return self.flow_head.run(pool, net[0], lazy=lazy) if update else None
 
     def run(self, pool, net, inp, corr, flow, motion, iter08=True, iter16=True, iter32=True, update=True):
         """`net`: list of S16 hidden states, updated IN PLACE; `inp`: per scale (cz, cr, cq) fp32; returns delta_flow (fp32)
@@ -527,9 +554,10 @@ class DispGradPredictor(nn.Module):
             pre.append(out)
         return pre
 
-    def run(self, pool, g5: torch.Tensor, cands: torch.Tensor, pre):
+    def run(self, pool, g5: torch.Tensor, cands: torch.Tensor, pre, lazy: bool = False):
         """g5 = 5 * gradient [N,2,H,W] fp32, cands [N,32,H,W] fp32, pre: `prepare(pool, clist)` of the 3 S16 context tensors
-        (64 ch at 1/4, 1/8, 1/16) -> (gradient fp32 [N,2,H,W], context S16 [N,64,H,W])."""
+        (64 ch at 1/4, 1/8, 1/16) -> (gradient fp32 [N,2,H,W], context S16 [N,64,H,W]).  `lazy`: the gradient as
+        (s16.Taps of residual_head[2], g5, 0.2) for DispRefine.run, which finishes (5*grad + residual) / 5 in its candidate stencil."""
         def feat(conv, srcs, share):
             n = sum(t.C for t in srcs)
             return conv16(pool, conv, srcs, act="relu", addend=share, pc=packed16_part(conv, ((0, n),), with_bias=False))
@@ -552,9 +580,14 @@ class DispGradPredictor(nn.Module):
         rh0, co0 = self.residual_head[0], self.conv_out[0]
         if "noheadfuse" not in _X and rh0.out_channels % 32 == 0:
             # residual_head[0] and conv_out[0] read the same x4_up (update.py:212-214): one 64 -> 128 + 64 launch whose epilogue
-            # sends the two channel ranges to their own S16 tensors — one launch and a fork / join less per iteration
-            h = pool.get((id(rh0), "o"), x4_up.B, rh0.out_channels, x4_up.H, x4_up.W, x4_up.device)
+            # sends the two channel ranges their own ways — one launch and a fork / join less per iteration
             ctx = pool.get((id(co0), "o"), x4_up.B, co0.out_channels, x4_up.H, x4_up.W, x4_up.device)
+            if "notaps" not in _X:
+                # ... and residual_head[2] (128 -> 2) is folded into that epilogue as tap partials: the 128-channel hidden tensor is
+                # never stored; (5*grad + residual) / 5 (update.py:213) is finished by the consumer
+                taps = tap_partials(pool, rh0, self.residual_head[2], [x4_up], pc=packed16_cat([rh0, co0]), out16b=ctx)
+                return ((taps, g5, 0.2) if lazy else s16.taps_sum(taps, addend=g5, scale=0.2)), ctx
+            h = pool.get((id(rh0), "o"), x4_up.B, rh0.out_channels, x4_up.H, x4_up.W, x4_up.device)
             s16.conv2d(packed16_cat([rh0, co0]), [x4_up], act="relu", out16=h, out16b=ctx, out16_split=rh0.out_channels)
             # (5*grad + residual) / 5 (update.py:213) in the epilogue of the last conv: addend = 5*grad, scale = 1/5
             return conv16(pool, self.residual_head[2], [h], addend=g5, post_scale=0.2, want32=True), ctx
@@ -599,7 +632,11 @@ class DispRefine(nn.Module):
         """-> (refined fp32, mask fp32 or None, dict(delta_disp, coords1, flow_x)).  With `motion`, the next iteration's flow input
         (coords1 - x) also lands in channel 127 of that S16 buffer (tc_stereo.py:180, update.py:126)."""
         def cand_branch():
-            f27, cand9 = s16.propagate_disparity(disp_grads, disp, out16=pool.get((id(self), "f27"), disp.shape[0], 27, disp.shape[2], disp.shape[3], disp.device))
+            f27 = pool.get((id(self), "f27"), disp.shape[0], 27, disp.shape[2], disp.shape[3], disp.device)
+            if isinstance(disp_grads, tuple):        # (tap partials of residual_head[2], 5*grad, 1/5) from DispGradPredictor.run(lazy=True)
+                f27, cand9, self._last_grad = s16.taps_propagate(disp_grads[0], disp_grads[1], disp_grads[2], disp, out16=f27)
+            else:
+                f27, cand9 = s16.propagate_disparity(disp_grads, disp, out16=f27)
             d = conv16(pool, self.disp_f_stem[0], [f27], act="relu")
             return cand9, conv16(pool, self.disp_f_stem[2], [d])
 

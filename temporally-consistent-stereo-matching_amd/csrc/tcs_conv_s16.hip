@@ -65,6 +65,7 @@ struct S16Args {
     _Float16* out16b; int out16b_groups, out16_split;   // LINEAR: channels >= out16_split go to this second S16 tensor (tcs_mi355.h)
     float* in_ws;                       // DECONV2X: InstanceNorm statistics of the output, see s16_deconv_stats() (nullable)
     float in_eps;
+    const float* tap_w; float* tap_out; int tap_nout, tap_ntile;   // LINEAR: tap partials of a following 3x3 conv to 1-2 channels (tcs_stencil.hip)
     int ablate;                         // diagnostic builds only (-DTCS_S16_ABLATE, tools/conv_s16_ablate.py): bit 0 skip the
                                         // input DMA, bit 1 skip the weight DMA, bit 2 skip operand reads + MFMAs (timing only)
 };
@@ -122,13 +123,32 @@ __device__ __forceinline__ void s16_epilogue_tile(const S16Args& a, int b, int c
             for (int r = 0; r < 16; ++r)
                 if (ok[r]) a.out32[((size_t)b * a.out_ctot + a.out_coff + cc[r]) * HW + pix] = v[r];
         }
-        if (a.out16) {
+        if (a.tap_out && (co0 >> 5) < a.tap_ntile) {
+            // tap partials (tcs_stencil.hip): P[tile][o*9 + t][pixel] = sum over this tile's 32 channels of w2[o][c][t] * v[c]; a lane holds
+            // 16 of them, its partner lane (+-32, same pixel) the other 16.  Weights in this lane half's register order.
+            const int tile = co0 >> 5, hh = (co0 >> 2) & 1, np = a.tap_nout * 9;
+            const float4_t* tw = reinterpret_cast<const float4_t*>(a.tap_w) + (size_t)(tile * 2 + hh) * np * 4;
+            float* tp = a.tap_out + ((size_t)(b * a.tap_ntile + tile) * np) * HW + pix;
+#pragma unroll 9
+            for (int ot = 0; ot < np; ++ot) {
+                const float4_t w0 = tw[ot * 4], w1 = tw[ot * 4 + 1], w2 = tw[ot * 4 + 2], w3 = tw[ot * 4 + 3];
+                float s = v[0] * w0[0];
+                s = fmaf(v[1], w0[1], s); s = fmaf(v[2], w0[2], s); s = fmaf(v[3], w0[3], s);
+                s = fmaf(v[4], w1[0], s); s = fmaf(v[5], w1[1], s); s = fmaf(v[6], w1[2], s); s = fmaf(v[7], w1[3], s);
+                s = fmaf(v[8], w2[0], s); s = fmaf(v[9], w2[1], s); s = fmaf(v[10], w2[2], s); s = fmaf(v[11], w2[3], s);
+                s = fmaf(v[12], w3[0], s); s = fmaf(v[13], w3[1], s); s = fmaf(v[14], w3[2], s); s = fmaf(v[15], w3[3], s);
+                const float other = __shfl_xor(s, 32);
+                if (hh == 0) tp[(size_t)ot * HW] = s + other;             // fixed order: lower half's 16 channels + upper half's
+            }
+        }
+        if (a.out16 || (a.out16b && co0 >= a.out16_split)) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int g = (co0 >> 3) + q, c_first = co0 + 8 * q;  // 4 consecutive channels c_first .. c_first + 3
                 if (c_first < a.Cout) {
                     // two layers in one launch: a tile (32 channels) lies wholly on one side of out16_split (a multiple of 32)
                     const bool second = a.out16b != nullptr && c_first >= a.out16_split;
+                    if (!second && !a.out16) continue;              // first range consumed as tap partials only
                     _Float16* o = second ? a.out16b + s16_unit(b, a.out16b_groups, g - (a.out16_split >> 3), 0, Hp, Wp, py, px) + sub4
                                          : a.out16 + s16_unit(b, a.out16_groups, a.out16_goff + g, 0, Hp, Wp, py, px) + sub4;
                     s16_store4(o, (size_t)Hp * Wp * 8, &v[4 * q], a.Cout - c_first);
@@ -263,7 +283,7 @@ __device__ __forceinline__ void s16_epilogue_tile(const S16Args& a, int b, int c
 #define S16_IN_WS_HEAD 16
 template <int MT, int ROWS>
 __device__ __forceinline__ void s16_deconv_stats(const S16Args& a, int b, int ct, int patch, int py, int px, int wave, int lane,
-                                                 const f32x16* acc, float* lds /* >= (ROWS * 64 + 8) floats, free to use */) {
+                                                 const f32x16* acc, float* lds /* >= max(ROWS * 64, 8 + 12 * C) floats, free to use */) {
     const int C = a.hidden, l31 = lane & 31, half = lane >> 5;
     const bool valid = px < a.W && py < a.H;
     const int ncol = min(32, a.W - (px - l31)), n_wave = py < a.H ? ncol : 0;       // wave-uniform: this row's valid pixels
@@ -343,20 +363,39 @@ __device__ __forceinline__ void s16_deconv_stats(const S16Args& a, int b, int ct
     if (reinterpret_cast<unsigned*>(lds)[0] == 0u) return;
     __threadfence();                                       // acquire: the other workgroups' slots
     const int tiles_per_par = C / 32;                      // C % 32 == 0 is checked by the launcher when statistics are requested
+    // one thread per (parity, channel): its npatch slots in patch order (the loads do not depend on the running merge, so they
+    // are unrolled and in flight together — one thread walking all 4 * npatch slots of a channel serialised ~100 memory round trips
+    // at the tail of the launch: +35 us); then the four parities of a channel in parity order, through LDS
+    for (int item = threadIdx.x; item < 4 * C; item += 64 * ROWS) {
+        const int par = item / C, c = item - par * C;
+        const float2_t* sl = reinterpret_cast<const float2_t*>(slots + (size_t)(par * tiles_per_par + (c >> 5)) * a.npatch * 64) + (c & 31);
+        float n = 0.f, mu = 0.f, q = 0.f;
+        int yy = 0, xx = 0;
+#pragma unroll 8
+        for (int p = 0; p < a.npatch; ++p) {
+            const float2_t s2 = sl[(size_t)p * 32];
+            const float ni = (float)(min(ROWS, a.H - yy) * min(32, a.W - xx));
+            const float tot = n + ni, f = ni / tot, dlt = s2[0] - mu;
+            mu += dlt * f;
+            q += s2[1] + dlt * dlt * n * f;
+            n = tot;
+            xx += 32;
+            if (xx >= a.W) { xx = 0; yy += ROWS; }
+        }
+        lds[8 + item * 3 + 0] = n;
+        lds[8 + item * 3 + 1] = mu;
+        lds[8 + item * 3 + 2] = q;
+    }
+    __syncthreads();
     for (int c = threadIdx.x; c < C; c += 64 * ROWS) {
         float n = 0.f, mu = 0.f, q = 0.f;
+#pragma unroll
         for (int par = 0; par < 4; ++par) {
-            const int tile = par * tiles_per_par + (c >> 5);
-            const float* sl = slots + (size_t)tile * a.npatch * 64 + (c & 31) * 2;
-            for (int p = 0; p < a.npatch; ++p) {
-                const int yy = (p / a.npx) * ROWS, xx = (p % a.npx) * 32;
-                const float ni = (float)(min(ROWS, a.H - yy) * min(32, a.W - xx));
-                const float mi = __builtin_nontemporal_load(sl + (size_t)p * 64), qi = __builtin_nontemporal_load(sl + (size_t)p * 64 + 1);
-                const float tot = n + ni, f = ni / tot, dlt = mi - mu;
-                mu += dlt * f;
-                q += qi + dlt * dlt * n * f;
-                n = tot;
-            }
+            const float ni = lds[8 + (par * C + c) * 3], mi = lds[8 + (par * C + c) * 3 + 1], qi = lds[8 + (par * C + c) * 3 + 2];
+            const float tot = n + ni, f = ni / tot, dlt = mi - mu;
+            mu += dlt * f;
+            q += qi + dlt * dlt * n * f;
+            n = tot;
         }
         finals[c * 2 + 0] = mu;
         finals[c * 2 + 1] = 1.0f / sqrtf(q / n + a.in_eps);
@@ -793,8 +832,13 @@ int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
     a.out16 = reinterpret_cast<_Float16*>(d->out16); a.out16_groups = d->out16_groups; a.out16_goff = d->out16_group_offset;
     a.out32 = d->out32; a.out_ctot = d->out_ctot; a.out_coff = d->out_coff;
     a.out16b = reinterpret_cast<_Float16*>(d->out16b); a.out16b_groups = d->out16b_groups; a.out16_split = d->out16_split;
+    a.tap_w = d->tap_weights; a.tap_out = d->tap_out; a.tap_nout = d->tap_nout; a.tap_ntile = d->tap_tiles;
+    if (a.tap_out) {
+        if (d->epilogue != TCS_EPI_LINEAR || stride != 1 || !a.tap_w || a.tap_nout < 1 || a.tap_nout > 2 || a.tap_ntile < 1 ||
+            a.tap_ntile > (d->Cout + 31) / 32) return TCS_EINVAL;
+    }
     if (a.out16b) {
-        if (d->epilogue != TCS_EPI_LINEAR || !a.out16 || a.out16_split <= 0 || a.out16_split % 32 != 0 || a.out16_split >= d->Cout) return TCS_EINVAL;
+        if (d->epilogue != TCS_EPI_LINEAR || (!a.out16 && !a.tap_out) || a.out16_split <= 0 || a.out16_split % 32 != 0 || a.out16_split >= d->Cout) return TCS_EINVAL;
         if (a.out16b_groups < (d->Cout - a.out16_split + 7) / 8) return TCS_EINVAL;
     }
     a.in_ws = d->in_stats; a.in_eps = d->in_eps;
@@ -804,7 +848,7 @@ int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
     a.ablate = d->tile_cfg / 1000000;                  // honoured by -DTCS_S16_ABLATE builds only
     a.bl_cand = nullptr; a.bl_cand_ctot = 0; a.bl_disp = nullptr; a.bl_refined = nullptr; a.bl_delta = nullptr; a.bl_coords1 = nullptr;
     a.bl_flow = nullptr; a.bl_f16 = nullptr; a.bl_f16_groups = 0; a.bl_f16_ch = 0;
-    if (!a.out16 && !a.out32 && d->epilogue != TCS_EPI_BLEND9) return TCS_EINVAL;
+    if (!a.out16 && !a.out32 && !a.tap_out && d->epilogue != TCS_EPI_BLEND9) return TCS_EINVAL;
     // the packed weight image pads K to a multiple of 64 channels (tcs_conv_packed_floats_f16x3): nk may not exceed it
     const int kpack = ((d->Cin + 63) / 64) * 4;
     int kst = 1;

@@ -248,6 +248,83 @@ __global__ __launch_bounds__(256) void k_propagate_s16(const float* __restrict__
     for (int g = 0; g < 4; ++g) s16_store8(out16 + s16_unit(b, Go, g, 0, H + 2, W + 2, y, x), plane, f + 8 * g);
 }
 
+
+// k_propagate_s16 with the refined gradient taken from tap partials (tcs_stencil.hip, "Tap partials"): residual_head[2] of the
+// gradient predictor never runs as a launch.  grad[o] = (g5[o] + bias[o] + taps[o]) * post_scale (core/update.py:213) is assembled for a
+// 16x16 pixel tile and its 1-pixel halo in LDS (clamped positions; the zero padding of update.py:277 is applied at use), written out
+// as the fp32 gradient, and the candidate stencil of update.py:259-289 runs from LDS.
+#define PT_T 16
+#define PT_S (PT_T + 2)
+__device__ __forceinline__ float taps_at_s16ops(const float* __restrict__ tp, int ntile, int nplanes, int o9, int gy, int gx, int H, int W) {
+    const size_t HW = (size_t)H * W;
+    float acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int qy = gy + t / 3 - 1, qx = gx + t % 3 - 1;
+        const bool in = qy >= 0 && qy < H && qx >= 0 && qx < W;
+        const int q = min(max(qy, 0), H - 1) * W + min(max(qx, 0), W - 1);
+        float s = 0.f;
+        for (int k = 0; k < ntile; ++k) s += tp[((size_t)k * nplanes + o9 + t) * HW + q];
+        acc += in ? s : 0.f;
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void k_taps_propagate_s16(const float* __restrict__ taps, int ntile, const float* __restrict__ bias,
+                                                             const float* __restrict__ g5, float post_scale, const float* __restrict__ disp,
+                                                             int H, int W, float* __restrict__ grad_out, float* __restrict__ cand9,
+                                                             _Float16* __restrict__ out16, int Go) {
+    __shared__ float sg[2][PT_S * PT_S];
+    const int b = blockIdx.z, HW = H * W;
+    const int tx0 = blockIdx.x * PT_T, ty0 = blockIdx.y * PT_T;
+    const float* tp = taps + (size_t)b * ntile * 18 * HW;
+    for (int e = threadIdx.x; e < PT_S * PT_S; e += 256) {
+        const int ey = e / PT_S, ex = e - ey * PT_S;
+        const int gy = min(max(ty0 + ey - 1, 0), H - 1), gx = min(max(tx0 + ex - 1, 0), W - 1), q = gy * W + gx;
+        const bool own = ey >= 1 && ey <= PT_T && ex >= 1 && ex <= PT_T && ty0 + ey - 1 < H && tx0 + ex - 1 < W;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            // same order of additions as k_taps_sum (tcs_stencil.hip): bit-equal to the materialised gradient
+            const float v = ((taps_at_s16ops(tp, ntile, 18, o * 9, gy, gx, H, W) + (bias ? bias[o] : 0.f)) + g5[((size_t)b * 2 + o) * HW + q]) * post_scale;
+            sg[o][e] = v;
+            if (own && grad_out) grad_out[((size_t)b * 2 + o) * HW + q] = v;
+        }
+    }
+    __syncthreads();
+    const int ly = threadIdx.x / PT_T, lx = threadIdx.x - ly * PT_T;
+    const int y = ty0 + ly, x = tx0 + lx;
+    if (y >= H || x >= W) return;
+    const int p = y * W + x;
+    const float* d = disp + (size_t)b * HW;
+    const float gcx = sg[0][(ly + 1) * PT_S + lx + 1], gcy = sg[1][(ly + 1) * PT_S + lx + 1];
+    float f[32];
+#pragma unroll
+    for (int k = 27; k < 32; ++k) f[k] = 0.f;
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int yy = y + v - 1, xx = x + u - 1;
+            const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const int q = min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1);
+            const float dn = d[q];                                                   // replicate pad
+            const float gnx = in ? sg[0][(ly + v) * PT_S + lx + u] : 0.f;            // zero pad
+            const float gny = in ? sg[1][(ly + v) * PT_S + lx + u] : 0.f;
+            const int k = 3 * v + u;
+            f[k] = dn + gnx * (float)(1 - u) + gny * (float)(1 - v);
+            f[9 + k] = fabsf(gcx - gnx);
+            f[18 + k] = fabsf(gcy - gny);
+        }
+    }
+    if (cand9) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) cand9[((size_t)b * 9 + k) * HW + p] = f[k];
+    }
+    const size_t plane = (size_t)(H + 2) * (W + 2) * 8;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) s16_store8(out16 + s16_unit(b, Go, g, 0, H + 2, W + 2, y, x), plane, f + 8 * g);
+}
+
 // one channel of an S16 tensor from a fp32 [B,1,H,W] tensor (the flow channel 127 of the motion features at frame start)
 __global__ __launch_bounds__(256) void k_s16_set_channel(const float* __restrict__ x, int H, int W, _Float16* __restrict__ out, int Go, int ch) {
     const int b = blockIdx.y, HW = H * W;
@@ -323,6 +400,14 @@ int tcs_propagate_disparity_s16(const float* grad, const float* disp, int B, int
     if (!grad || !disp || !out16 || out_groups < 4 || B <= 0 || B > 65535 || H <= 0 || W <= 0) return TCS_EINVAL;
     hipLaunchKernelGGL(k_propagate_s16, dim3(tcs_cdiv((long long)H * W, 256), B), dim3(256), 0, tcs_stream(stream), grad, disp, H, W, cand9,
                        reinterpret_cast<_Float16*>(out16), out_groups);
+    return tcs_launch_status();
+}
+
+int tcs_taps_propagate_s16(const float* taps, int ntile, const float* bias2, const float* g5, float post_scale, const float* disp, int B, int H,
+                           int W, float* grad_out, float* cand9, void* out16, int out_groups, tcs_stream_t stream) {
+    if (!taps || !g5 || !disp || !out16 || ntile <= 0 || out_groups < 4 || B <= 0 || B > 65535 || H <= 0 || W <= 0) return TCS_EINVAL;
+    hipLaunchKernelGGL(k_taps_propagate_s16, dim3(tcs_cdiv(W, PT_T), tcs_cdiv(H, PT_T), B), dim3(256), 0, tcs_stream(stream), taps, ntile, bias2,
+                       g5, post_scale, disp, H, W, grad_out, cand9, reinterpret_cast<_Float16*>(out16), out_groups);
     return tcs_launch_status();
 }
 

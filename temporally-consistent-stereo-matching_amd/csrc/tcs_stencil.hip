@@ -237,7 +237,151 @@ __global__ __launch_bounds__(256) void k_avgpool3s2(const float* __restrict__ x,
     out[(size_t)bc * Ho * Wo + p] = acc / 9.f;
 }
 
+
+// =====================================================================================================================
+// "Tap partials": a 3x3 convolution with ONE or TWO output channels that follows a wide convolution (FlowHead.conv2, 256 -> 1,
+// core/update.py:13-17; DispGradPredictor.residual_head[2], 128 -> 2, core/update.py:196,213) never runs as a launch of its own.
+//   out[o][p] = b[o] + sum_t sum_c w[o][c][t] * y[c][p + d(t)],   d(t) = (t/3 - 1, t%3 - 1), y = 0 outside the image
+// The producer of y (tcs_conv2d_s16, tap_* fields) holds 32 channels of y per workgroup in registers and leaves
+//   P[b][tile][o*9 + t][q] = sum_{c in tile} w[o][c][t] * y[c][q]
+// per source pixel q — 9 (18) fp32 planes per 32-channel tile instead of the 256 (128) channels of y.  The consumer sums the planes
+// in a fixed order (tile-major inside a tap: results do not depend on scheduling) at q = p + d(t) inside the image.  Three consumers:
+// the plain sum (API paths), the flow-step / gradient stencils of an iteration, and DispRefine's candidate stencil.
+// =====================================================================================================================
+__device__ __forceinline__ float taps_at(const float* __restrict__ tp /* [ntile][nout*9][HW] of this batch element */, int ntile, int nplanes,
+                                         int o9, int gy, int gx, int H, int W) {
+    const size_t HW = (size_t)H * W;
+    float acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int qy = gy + t / 3 - 1, qx = gx + t % 3 - 1;
+        const bool in = qy >= 0 && qy < H && qx >= 0 && qx < W;
+        const int q = min(max(qy, 0), H - 1) * W + min(max(qx, 0), W - 1);
+        float s = 0.f;
+        for (int k = 0; k < ntile; ++k) s += tp[((size_t)k * nplanes + o9 + t) * HW + q];
+        acc += in ? s : 0.f;
+    }
+    return acc;
+}
+
+// out[b][o][p] = (addend[b][o][p] + bias[o] + taps) * scale
+__global__ __launch_bounds__(256) void k_taps_sum(const float* __restrict__ taps, int ntile, int nout, const float* __restrict__ bias,
+                                                  const float* __restrict__ addend, float scale, int H, int W, float* __restrict__ out) {
+    const int b = blockIdx.y, HW = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const int y = p / W, x = p - y * W;
+    const float* tp = taps + (size_t)b * ntile * nout * 9 * HW;
+    for (int o = 0; o < nout; ++o) {
+        float v = taps_at(tp, ntile, nout * 9, o * 9, y, x, H, W) + (bias ? bias[o] : 0.f);
+        if (addend) v += addend[((size_t)b * nout + o) * HW + p];
+        out[((size_t)b * nout + o) * HW + p] = v * scale;
+    }
+}
+
+// k_flow_step_grads with delta = FlowHead.conv2's output taken from tap partials (+ bias): the disparity of a 16x16 pixel tile and its
+// 2-pixel halo is assembled once in LDS (positions outside the image hold the value of the clamped position: the replicate padding
+// of geo_utils.py:117; the zero padding of geo_utils.py:91 is applied where the candidates are formed), then the three stencils
+// run from LDS.  Also emits delta itself (nullable) for callers that want FlowHead's output as a tensor.
+#define FT_T 16
+#define FT_S (FT_T + 4)
+__global__ __launch_bounds__(256) void k_flow_taps_step_grads(const float* __restrict__ coords1, const float* __restrict__ taps, int ntile,
+                                                              const float* __restrict__ bias, int H, int W, float scale,
+                                                              float* __restrict__ disp_q, float* __restrict__ grad, float* __restrict__ cands,
+                                                              float* __restrict__ delta_out) {
+    __shared__ float sd[FT_S * FT_S];
+    const int b = blockIdx.z, HW = H * W;
+    const int tx0 = blockIdx.x * FT_T, ty0 = blockIdx.y * FT_T;
+    const float* c1 = coords1 + (size_t)b * HW;
+    const float* tp = taps + (size_t)b * ntile * 9 * HW;
+    const float bs = bias ? bias[0] : 0.f;
+    for (int e = threadIdx.x; e < FT_S * FT_S; e += 256) {
+        const int ey = e / FT_S, ex = e - ey * FT_S;
+        const int gy = min(max(ty0 + ey - 2, 0), H - 1), gx = min(max(tx0 + ex - 2, 0), W - 1);
+        const float dl = taps_at(tp, ntile, 9, 0, gy, gx, H, W) + bs;
+        sd[e] = (float)gx - (c1[gy * W + gx] + dl);
+        if (delta_out && ey >= 2 && ey < FT_T + 2 && ex >= 2 && ex < FT_T + 2 && ty0 + ey - 2 < H && tx0 + ex - 2 < W)
+            delta_out[(size_t)b * HW + gy * W + gx] = dl;
+    }
+    __syncthreads();
+    const int ly = threadIdx.x / FT_T, lx = threadIdx.x - ly * FT_T;
+    const int y = ty0 + ly, x = tx0 + lx;
+    if (y >= H || x >= W) return;
+    const int p = y * W + x;
+#define FT_D(DY, DX) sd[(ly + 2 + (DY)) * FT_S + (lx + 2 + (DX))]
+    const float c = FT_D(0, 0);
+    disp_q[(size_t)b * HW + p] = c;
+    grad[((size_t)b * 2 + 0) * HW + p] = scale * (FT_D(0, 1) - c);
+    grad[((size_t)b * 2 + 1) * HW + p] = scale * (FT_D(1, 0) - c);
+    const int dv[8] = {-1, -1, -1, 0, 1, 1, 1, 0};
+    const int du[8] = {-1, 0, 1, 1, 1, 0, -1, -1};
+    float vx[16], vy[16], vz[16];
+#pragma unroll
+    for (int s = 1; s <= 2; ++s) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int yy = y + s * dv[k], xx = x + s * du[k];
+            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const float nb = ok ? FT_D(s * dv[k], s * du[k]) : 0.f;
+            const int i = (s - 1) * 8 + k;
+            vx[i] = (float)(s * du[k]);
+            vy[i] = (float)(s * dv[k]);
+            vz[i] = nb - c;
+        }
+    }
+#undef FT_D
+    float* o = cands + (size_t)b * 32 * HW + p;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int r = (k + 2) & 15;
+        const float nx = vy[k] * vz[r] - vz[k] * vy[r];
+        const float ny = vz[k] * vx[r] - vx[k] * vz[r];
+        const float nz = vx[k] * vy[r] - vy[k] * vx[r];
+        o[(size_t)k * HW] = -nx / nz;
+        o[(size_t)(16 + k) * HW] = -ny / nz;
+    }
+}
+
+// [nout][C][3][3] fp32 -> the producer's per-lane order: tw[tile][half][o*9 + t][r], channel = 32*tile + 4*half + (r&3) + 8*(r>>2)
+// (register r of a 32x32 accumulator tile, csrc/tcs_conv_s16.hip), zero beyond C
+__global__ __launch_bounds__(256) void k_pack_tap_weights(const float* __restrict__ w, int nout, int C, int ntile, float* __restrict__ packed) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ntile * 2 * nout * 9 * 16) return;
+    const int r = i & 15, ot = (i >> 4) % (nout * 9), half = ((i >> 4) / (nout * 9)) & 1, tile = (i >> 4) / (nout * 9) / 2;
+    const int c = 32 * tile + 4 * half + (r & 3) + 8 * (r >> 2), o = ot / 9, t = ot - o * 9;
+    packed[i] = c < C ? w[((size_t)o * C + c) * 9 + t] : 0.f;
+}
+
 extern "C" {
+
+size_t tcs_tap_weights_floats(int nout, int C) {
+    if (nout < 1 || nout > 2 || C <= 0) return 0;
+    return (size_t)((C + 31) / 32) * 2 * nout * 9 * 16;
+}
+
+int tcs_pack_tap_weights(const float* w_oihw, int nout, int C, float* packed, tcs_stream_t stream) {
+    if (!w_oihw || !packed || nout < 1 || nout > 2 || C <= 0) return TCS_EINVAL;
+    const int ntile = (C + 31) / 32, n = ntile * 2 * nout * 9 * 16;
+    hipLaunchKernelGGL(k_pack_tap_weights, dim3((n + 255) / 256), dim3(256), 0, tcs_stream(stream), w_oihw, nout, C, ntile, packed);
+    return tcs_launch_status();
+}
+
+int tcs_taps_sum(const float* taps, int ntile, int nout, const float* bias, const float* addend, float scale, int B, int H, int W, float* out,
+                 tcs_stream_t stream) {
+    if (!taps || !out || ntile <= 0 || nout < 1 || nout > 2 || B <= 0 || B > 65535 || H <= 0 || W <= 0) return TCS_EINVAL;
+    hipLaunchKernelGGL(k_taps_sum, dim3(tcs_cdiv((long long)H * W, 256), B), dim3(256), 0, tcs_stream(stream), taps, ntile, nout, bias, addend,
+                       scale, H, W, out);
+    return tcs_launch_status();
+}
+
+int tcs_flow_taps_step_grads(const float* coords1, const float* taps, int ntile, const float* bias, int B, int H, int W, float scale,
+                             float* disp_q, float* grad, float* cands, float* delta_out, tcs_stream_t stream) {
+    if (!coords1 || !taps || !disp_q || !grad || !cands || ntile <= 0 || B <= 0 || B > 65535 || H <= 0 || W <= 0) return TCS_EINVAL;
+    hipLaunchKernelGGL(k_flow_taps_step_grads, dim3(tcs_cdiv(W, FT_T), tcs_cdiv(H, FT_T), B), dim3(256), 0, tcs_stream(stream), coords1, taps,
+                       ntile, bias, H, W, scale, disp_q, grad, cands, delta_out);
+    return tcs_launch_status();
+}
+
 
 int tcs_flow_step(float* coords1, const float* delta, int B, int H, int W, float* disp_q, tcs_stream_t stream) {
     if (!coords1 || !delta || !disp_q || B <= 0 || H <= 0 || W <= 0) return TCS_EINVAL;

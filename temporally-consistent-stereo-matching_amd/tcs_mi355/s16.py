@@ -161,16 +161,18 @@ def _out_grid(s: S16, stride: int):
 def conv2d(pc: PackedConv, srcs: Sequence[S16], act: str = "none", addend: Optional[torch.Tensor] = None, post_scale: float = 1.0,
            out16: Optional[S16] = None, out16_group_offset: int = 0, out32: Optional[torch.Tensor] = None, out_coff: int = 0,
            stride: int = 1, want32: bool = False, tile_cfg: int = 0, addend16: Optional[S16] = None, addend_ctot: int = 0,
-           out16b: Optional[S16] = None, out16_split: int = 0):
+           out16b: Optional[S16] = None, out16_split: int = 0, taps: Optional["Taps"] = None, tap_weights: Optional[torch.Tensor] = None):
     """act(conv(cat(srcs)) + bias + addend) * post_scale -> S16 (`out16`, allocated when neither output is given)
     and/or fp32 NCHW (`out32`, or allocated when want32).  Returns (out16, out32).  `addend_ctot` > Cout: `addend` is a
     channel slice of a [B, addend_ctot, Ho, Wo] tensor (pass the sliced view).  `out16b`: output channels from `out16_split`
-    (a multiple of 32) on go to this second S16 tensor — two layers over the same input as one launch."""
+    (a multiple of 32) on go to this second S16 tensor — two layers over the same input as one launch.  `taps` + `tap_weights`
+    (`pack_taps`): the launch also leaves the tap partials of a following 3x3 convolution to 1-2 channels for the first `taps.ntile`
+    32-channel tiles (tcs_conv_s16_desc.tap_*); `out16` is then optional."""
     d = _desc(pc, srcs, stride)
     Ho, Wo = _out_grid(srcs[0], stride)
     if out32 is None and want32:
         out32 = torch.empty(d.B, pc.cout, Ho, Wo, dtype=torch.float32, device=srcs[0].device)
-    if out16 is None and out32 is None:
+    if out16 is None and out32 is None and taps is None:
         out16 = zeros(d.B, pc.cout, Ho, Wo, srcs[0].device)
     if out16 is not None and (out16.B, out16.H, out16.W) != (d.B, Ho, Wo):
         raise ValueError("conv2d: bad `out16` grid")
@@ -187,9 +189,15 @@ def conv2d(pc: PackedConv, srcs: Sequence[S16], act: str = "none", addend: Optio
     if out16 is not None:
         d.out16, d.out16_groups, d.out16_group_offset = out16.ptr(), out16.G, int(out16_group_offset)
     if out16b is not None:
-        if out16 is None or (out16b.B, out16b.H, out16b.W) != (d.B, Ho, Wo):
-            raise ValueError("conv2d: `out16b` needs `out16` and the same grid")
+        if (out16 is None and taps is None) or (out16b.B, out16b.H, out16b.W) != (d.B, Ho, Wo):
+            raise ValueError("conv2d: `out16b` needs `out16` (or `taps`) and the same grid")
         d.out16b, d.out16b_groups, d.out16_split = out16b.ptr(), out16b.G, int(out16_split)
+    if taps is not None:
+        if tap_weights is None or tuple(taps.data.shape) != (d.B, taps.ntile, 9 * taps.nout, Ho, Wo):
+            raise ValueError("conv2d: `taps` needs `tap_weights` and a [B, ntile, 9*nout, H, W] buffer")
+        if tap_weights.numel() < nv.lib().tcs_tap_weights_floats(taps.nout, 32 * taps.ntile):
+            raise ValueError("conv2d: `tap_weights` too small")
+        d.tap_weights, d.tap_out, d.tap_nout, d.tap_tiles = nv.ptr(tap_weights, "tap_weights"), nv.ptr(taps.data, "taps"), taps.nout, taps.ntile
     if out32 is not None:
         d.out32, d.out_ctot, d.out_coff = nv.ptr(out32, "out32"), int(out32.shape[1]), int(out_coff)
     d.tile_cfg = int(tile_cfg)
@@ -338,6 +346,68 @@ def propagate_disparity(grad: torch.Tensor, disp: torch.Tensor, out16: Optional[
     nv.check(nv.lib().tcs_propagate_disparity_s16(nv.ptr(grad, "grad"), nv.ptr(disp, "disp"), B, H, W, nv.ptr(cand9), out16.ptr(), out16.G,
                                                   nv.stream()), "tcs_propagate_disparity_s16")
     return out16, cand9
+
+
+# ---------------------------------------------------------------------------------------------
+# tap partials: a 3x3 convolution to 1-2 channels folded into its producer (csrc/tcs_stencil.hip)
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class Taps:
+    """What a `conv2d(..., taps=)` launch leaves for the 3x3 convolution that follows it: fp32 [B, ntile, 9*nout, H, W] partial sums per
+    32-channel tile of its output, + that convolution's bias.  Consumers: `taps_sum`, `flow_taps_step_grads`, `taps_propagate`."""
+    data: torch.Tensor
+    ntile: int
+    nout: int
+    bias: Optional[torch.Tensor] = None
+
+
+def pack_taps(weight: torch.Tensor) -> torch.Tensor:
+    """[nout, C, 3, 3] weights of the folded convolution -> the producer's per-lane order (tcs_pack_tap_weights)."""
+    nout, C_ = int(weight.shape[0]), int(weight.shape[1])
+    if tuple(weight.shape[2:]) != (3, 3) or nout not in (1, 2):
+        raise ValueError("pack_taps: a 3x3 convolution with 1 or 2 output channels")
+    w = weight.detach().float().contiguous()
+    out = torch.empty(nv.lib().tcs_tap_weights_floats(nout, C_), dtype=torch.float32, device=w.device)
+    nv.check(nv.lib().tcs_pack_tap_weights(nv.ptr(w, "weight"), nout, C_, nv.ptr(out), nv.stream()), "tcs_pack_tap_weights")
+    return out
+
+
+def taps_sum(t: Taps, addend: Optional[torch.Tensor] = None, scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(addend + bias + folded convolution) * scale -> fp32 [B, nout, H, W]."""
+    B, _, _, H, W = (int(v) for v in t.data.shape)
+    out = torch.empty(B, t.nout, H, W, dtype=torch.float32, device=t.data.device) if out is None else out
+    nv.check(nv.lib().tcs_taps_sum(nv.ptr(t.data, "taps"), t.ntile, t.nout, nv.ptr(t.bias), nv.ptr(addend, "addend"), float(scale), B, H, W,
+                                   nv.ptr(out, "out"), nv.stream()), "tcs_taps_sum")
+    return out
+
+
+def flow_taps_step_grads(coords1: torch.Tensor, t: Taps, scale: float = 1.0, want_delta: bool = False):
+    """`ops.flow_step_grads` with delta = FlowHead's output taken from tap partials -> (disp_q, scale * gradient, candidates[, delta])."""
+    B, _, H, W = (int(v) for v in coords1.shape)
+    if t.nout != 1 or tuple(t.data.shape[3:]) != (H, W):
+        raise ValueError("flow_taps_step_grads: single-output taps on the coords grid")
+    dq = torch.empty(B, 1, H, W, dtype=torch.float32, device=coords1.device)
+    g = torch.empty(B, 2, H, W, dtype=torch.float32, device=coords1.device)
+    c = torch.empty(B, 32, H, W, dtype=torch.float32, device=coords1.device)
+    dl = torch.empty_like(dq) if want_delta else None
+    nv.check(nv.lib().tcs_flow_taps_step_grads(nv.ptr(coords1, "coords1"), nv.ptr(t.data, "taps"), t.ntile, nv.ptr(t.bias), B, H, W, float(scale),
+                                               nv.ptr(dq), nv.ptr(g), nv.ptr(c), nv.ptr(dl), nv.stream()), "tcs_flow_taps_step_grads")
+    return (dq, g, c, dl) if want_delta else (dq, g, c)
+
+
+def taps_propagate(t: Taps, g5: torch.Tensor, post_scale: float, disp: torch.Tensor, out16: Optional[S16] = None,
+                   cand9: Optional[torch.Tensor] = None, grad: Optional[torch.Tensor] = None):
+    """`propagate_disparity` with the gradient (g5 + bias + folded residual convolution) * post_scale (update.py:213) taken from tap
+    partials -> (S16 stem input, fp32 candidates, fp32 gradient [B,2,H,W])."""
+    B, _, H, W = (int(v) for v in disp.shape)
+    if t.nout != 2 or tuple(t.data.shape[3:]) != (H, W) or tuple(g5.shape) != (B, 2, H, W):
+        raise ValueError("taps_propagate: two-output taps and a [B,2,H,W] gradient on the disparity grid")
+    out16 = zeros(B, 27, H, W, disp.device) if out16 is None else out16
+    cand9 = torch.empty(B, 9, H, W, dtype=torch.float32, device=disp.device) if cand9 is None else cand9
+    grad = torch.empty(B, 2, H, W, dtype=torch.float32, device=disp.device) if grad is None else grad
+    nv.check(nv.lib().tcs_taps_propagate_s16(nv.ptr(t.data, "taps"), t.ntile, nv.ptr(t.bias), nv.ptr(g5, "g5"), float(post_scale), nv.ptr(disp, "disp"),
+                                             B, H, W, nv.ptr(grad), nv.ptr(cand9), out16.ptr(), out16.G, nv.stream()), "tcs_taps_propagate_s16")
+    return out16, cand9, grad
 
 
 def set_channel(x: torch.Tensor, out: S16, channel: int) -> S16:

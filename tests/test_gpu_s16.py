@@ -428,3 +428,48 @@ def test_deconv_fused_instance_norm_statistics(dev):
                 got = s16.instance_norm_apply(y, ws, act="leaky", addend=rem16, out=y)
                 assert got is y and maxdiff(y.float(), two.float()) <= 2e-6, (cout, tc)
                 assert maxdiff(y.float(), ref) <= 3e-5, (cout, tc)
+
+
+def test_tap_partials_fold_a_narrow_3x3_convolution_into_its_producer(dev):
+    """tcs_conv_s16_desc.tap_*: FlowHead.conv2 (256 -> 1) and residual_head[2] (128 -> 2) never run as launches (update.py:13-17,196,213).
+    The producer's tap partials, summed by tcs_taps_sum, must equal conv2(relu(conv1(x))) (fp64 reference); the two fused consumers
+    must equal the unfused kernels fed with that sum, bit for bit (same additions in the same order)."""
+    from tcs_mi355 import ops, s16
+    gen = torch.Generator().manual_seed(31)
+    for (cin, cmid, nout, H, W, B, extra) in ((128, 256, 1, 21, 45, 1, 0), (64, 128, 2, 18, 37, 2, 64), (32, 40, 1, 9, 33, 1, 0)):
+        x = torch.randn(B, cin, H, W, generator=gen)
+        w1 = torch.randn(cmid + extra, cin, 3, 3, generator=gen) * (2.0 / (9 * cin)) ** 0.5
+        b1 = torch.randn(cmid + extra, generator=gen) * 0.1
+        w2 = torch.randn(nout, cmid, 3, 3, generator=gen) * (2.0 / (9 * cmid)) ** 0.5
+        b2 = torch.randn(nout, generator=gen) * 0.1
+        y = torch.relu(F.conv2d(x.double(), w1.double(), b1.double(), padding=1))
+        ref = F.conv2d(y[:, :cmid], w2.double(), b2.double(), padding=1)
+        pc = ops.pack_conv(D(w1, dev), D(b1, dev), "f16x3")
+        ntile = (cmid + 31) // 32
+        taps = s16.Taps(torch.empty(B, ntile, 9 * nout, H, W, device=dev), ntile, nout, D(b2, dev))
+        x16 = s16.to_s16(D(x, dev))
+        second = s16.zeros(B, extra, H, W, dev) if extra else None
+        for tc in (0, 1412, 101812):
+            taps.data.fill_(float("nan"))
+            s16.conv2d(pc, [x16], act="relu", taps=taps, tap_weights=s16.pack_taps(D(w2, dev)), out16b=second, out16_split=cmid if extra else 0,
+                       tile_cfg=tc)
+            got = s16.taps_sum(taps)
+            assert maxdiff(got, ref) <= 3e-5, (cmid, nout, tc)
+            if extra:
+                assert maxdiff(second.float(), y[:, cmid:]) <= 2e-5
+        add = torch.randn(B, nout, H, W, generator=gen)
+        assert maxdiff(s16.taps_sum(taps, addend=D(add, dev), scale=0.2), (ref + add.double()) * 0.2) <= 1e-5
+        if nout == 1:
+            c1 = torch.arange(W, dtype=torch.float32).view(1, 1, 1, W).expand(B, 1, H, W) - torch.rand(B, 1, H, W, generator=gen) * 30
+            c1 = D(c1.contiguous(), dev)
+            dq, g, c, dl = s16.flow_taps_step_grads(c1, taps, scale=5.0, want_delta=True)
+            assert torch.equal(dl, got)
+            for a, b in zip((dq, g, c), ops.flow_step_grads(c1, got, scale=5.0)):
+                assert torch.equal(torch.nan_to_num(a, nan=7.0, posinf=8.0, neginf=9.0), torch.nan_to_num(b, nan=7.0, posinf=8.0, neginf=9.0))
+        else:
+            g5 = D(torch.randn(B, 2, H, W, generator=gen), dev)
+            disp = D(torch.rand(B, 1, H, W, generator=gen) * 40, dev)
+            grad_ref = s16.taps_sum(taps, addend=g5, scale=0.2)
+            o16, c9, grad = s16.taps_propagate(taps, g5, 0.2, disp)
+            r16, r9 = s16.propagate_disparity(grad_ref, disp)
+            assert torch.equal(grad, grad_ref) and torch.equal(c9, r9) and torch.equal(o16.data, r16.data)
