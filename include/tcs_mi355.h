@@ -374,6 +374,7 @@ typedef struct tcs_conv_s16_desc {
     const float* tap_weights;
     float* tap_out;
     int tap_nout, tap_tiles;
+    float tap_unscale;              /* 2^-scale_log2 given to tcs_pack_tap_weights */
 } tcs_conv_s16_desc;
 
 /* S16 glue of the loop: pool2x / interp (core/update.py:114-124), the up-blocks' InstanceNorm + LeakyReLU + skip
@@ -390,13 +391,14 @@ int tcs_instance_norm_s16(const void* x, int B, int groups, int H, int W, float 
 size_t tcs_deconv_in_stats_bytes(int B, int C, int H_in, int W_in);
 int tcs_instance_norm_apply_s16(const void* x, int B, int groups, int H, int W, int act, const void* addend, int addend_groups,
                                 void* out, int out_groups, const float* in_stats, int C, tcs_stream_t stream);
-/* Tap partials (tcs_conv_s16_desc.tap_*): weights [nout][C][3][3] -> the producer's order (tcs_tap_weights_floats floats);
+/* Tap partials (tcs_conv_s16_desc.tap_*): weights [nout][C][3][3] * 2^scale_log2 -> fp16-split MFMA A fragments in the producer's
+ * accumulator channel order, rows o*9 + t (tcs_tap_weights_floats floats; choose scale_log2 like tcs_pack_conv_weight_f16x3);
  * tcs_taps_sum: out[B,nout,H,W] = (addend + bias + sum over tiles and in-image taps) * scale (addend, bias nullable);
  * tcs_flow_taps_step_grads = tcs_flow_step_grads with delta = bias[0] + taps (FlowHead's output, also written to delta_out when
  * non-NULL); tcs_taps_propagate_s16 = tcs_propagate_disparity_s16 with grad = (g5 + bias2 + taps) * post_scale (core/update.py:213),
  * also written to grad_out [B,2,H,W] when non-NULL. */
 size_t tcs_tap_weights_floats(int nout, int C);
-int tcs_pack_tap_weights(const float* w_oihw, int nout, int C, float* packed, tcs_stream_t stream);
+int tcs_pack_tap_weights(const float* w_oihw, int nout, int C, int scale_log2, float* packed, tcs_stream_t stream);
 int tcs_taps_sum(const float* taps, int ntile, int nout, const float* bias, const float* addend, float scale, int B, int H, int W, float* out,
                  tcs_stream_t stream);
 int tcs_flow_taps_step_grads(const float* coords1, const float* taps, int ntile, const float* bias, int B, int H, int W, float scale,

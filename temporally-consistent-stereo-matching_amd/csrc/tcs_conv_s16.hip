@@ -66,6 +66,7 @@ struct S16Args {
     float* in_ws;                       // DECONV2X: InstanceNorm statistics of the output, see s16_deconv_stats() (nullable)
     float in_eps;
     const float* tap_w; float* tap_out; int tap_nout, tap_ntile;   // LINEAR: tap partials of a following 3x3 conv to 1-2 channels (tcs_stencil.hip)
+    float tap_unscale;
     int ablate;                         // diagnostic builds only (-DTCS_S16_ABLATE, tools/conv_s16_ablate.py): bit 0 skip the
                                         // input DMA, bit 1 skip the weight DMA, bit 2 skip operand reads + MFMAs (timing only)
 };
@@ -80,6 +81,13 @@ __device__ __forceinline__ void s16_epilogue_tile(const S16Args& a, int b, int c
     const int H = a.H, W = a.W;
     const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
     const int Hp = H + 2, Wp = W + 2;
+    // tap partials: this tile's four weight fragments (k-steps 2*tile, 2*tile + 1; hi, lo) are requested first, used last
+    const bool taps_here = EPI == TCS_EPI_LINEAR && a.tap_out != nullptr && (co0 >> 5) < a.tap_ntile;
+    uint4 tw0h = {0, 0, 0, 0}, tw0l = {0, 0, 0, 0}, tw1h = {0, 0, 0, 0}, tw1l = {0, 0, 0, 0};
+    if (taps_here) {
+        const uint4* twp = reinterpret_cast<const uint4*>(a.tap_w) + (size_t)(co0 >> 5) * 256 + (threadIdx.x & 63);
+        tw0h = twp[0]; tw0l = twp[64]; tw1h = twp[128]; tw1l = twp[192];
+    }
     int cc[16];
     bool ok[16];
     float v[16];
@@ -123,22 +131,32 @@ __device__ __forceinline__ void s16_epilogue_tile(const S16Args& a, int b, int c
             for (int r = 0; r < 16; ++r)
                 if (ok[r]) a.out32[((size_t)b * a.out_ctot + a.out_coff + cc[r]) * HW + pix] = v[r];
         }
-        if (a.tap_out && (co0 >> 5) < a.tap_ntile) {
-            // tap partials (tcs_stencil.hip): P[tile][o*9 + t][pixel] = sum over this tile's 32 channels of w2[o][c][t] * v[c]; a lane holds
-            // 16 of them, its partner lane (+-32, same pixel) the other 16.  Weights in this lane half's register order.
-            const int tile = co0 >> 5, hh = (co0 >> 2) & 1, np = a.tap_nout * 9;
-            const float4_t* tw = reinterpret_cast<const float4_t*>(a.tap_w) + (size_t)(tile * 2 + hh) * np * 4;
-            float* tp = a.tap_out + ((size_t)(b * a.tap_ntile + tile) * np) * HW + pix;
-#pragma unroll 9
-            for (int ot = 0; ot < np; ++ot) {
-                const float4_t w0 = tw[ot * 4], w1 = tw[ot * 4 + 1], w2 = tw[ot * 4 + 2], w3 = tw[ot * 4 + 3];
-                float s = v[0] * w0[0];
-                s = fmaf(v[1], w0[1], s); s = fmaf(v[2], w0[2], s); s = fmaf(v[3], w0[3], s);
-                s = fmaf(v[4], w1[0], s); s = fmaf(v[5], w1[1], s); s = fmaf(v[6], w1[2], s); s = fmaf(v[7], w1[3], s);
-                s = fmaf(v[8], w2[0], s); s = fmaf(v[9], w2[1], s); s = fmaf(v[10], w2[2], s); s = fmaf(v[11], w2[3], s);
-                s = fmaf(v[12], w3[0], s); s = fmaf(v[13], w3[1], s); s = fmaf(v[14], w3[2], s); s = fmaf(v[15], w3[3], s);
-                const float other = __shfl_xor(s, 32);
-                if (hh == 0) tp[(size_t)ot * HW] = s + other;             // fixed order: lower half's 16 channels + upper half's
+        if (taps_here) {
+            // tap partials (tcs_stencil.hip): P[tile][o*9 + t][pixel] = sum over this tile's 32 channels of w2[o][c][t] * v[c] — a 32 (rows
+            // o*9 + t, <= 18 real) x 32 (channels) x 32 (pixels) product: the activated accumulator registers 8s .. 8s+7 ARE the B fragment
+            // of k-step s (the register-chain of k_hidden_update_s16; weights packed in that channel order by tcs_pack_tap_weights), so the
+            // fold costs 6 MFMAs and one round trip for the 4 weight fragments (fetched at the top of the epilogue).  A first version
+            // with 9 x (4 weight loads -> 16 FMAs -> cross-half shuffle -> store) serialised 9 memory round trips per wave: +1.2 ms per frame.
+            half8 bh0, bl0, bh1, bl1;
+            split8(v, bh0, bl0);
+            split8(v + 8, bh1, bl1);
+            f32x16 pa;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pa[i] = 0.f;
+            const half8 a0h = *reinterpret_cast<const half8*>(&tw0h), a0l = *reinterpret_cast<const half8*>(&tw0l);
+            const half8 a1h = *reinterpret_cast<const half8*>(&tw1h), a1l = *reinterpret_cast<const half8*>(&tw1l);
+            pa = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0l, bh0, pa, 0, 0, 0);
+            pa = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bl0, pa, 0, 0, 0);
+            pa = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, bh0, pa, 0, 0, 0);
+            pa = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1l, bh1, pa, 0, 0, 0);
+            pa = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bl1, pa, 0, 0, 0);
+            pa = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, bh1, pa, 0, 0, 0);
+            const int np = a.tap_nout * 9;
+            float* tp = a.tap_out + ((size_t)(b * a.tap_ntile + (co0 >> 5)) * np) * HW + pix;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {                 // row of register r: (co0 & 4) + (r&3) + 8*(r>>2)
+                const int ot = (co0 & 4) + (r & 3) + 8 * (r >> 2);
+                if (ot < np) tp[(size_t)ot * HW] = pa[r] * a.tap_unscale;
             }
         }
         if (a.out16 || (a.out16b && co0 >= a.out16_split)) {
@@ -345,39 +363,42 @@ __device__ __forceinline__ void s16_deconv_stats(const S16Args& a, int b, int ct
             }
             // channel of (half, r) inside the tile: 4*half + (r&3) + 8*(r>>2)
             const int hh = lane >> 4, r = lane & 15, cin_tile = 4 * hh + (r & 3) + 8 * (r >> 2);
+            // device-coherent (write-through) stores: the slots cross XCDs without an L2 write-back.  (A __threadfence() per workgroup —
+            // an L2 write-back of everything dirty, i.e. of the output tensor being written — cost ~20 us per launch.)
             float* sl = slots + ((size_t)(ct * MT + m) * a.npatch + patch) * 64;
-            sl[cin_tile * 2 + 0] = mu;
-            sl[cin_tile * 2 + 1] = q;
+            __hip_atomic_store(sl + cin_tile * 2 + 0, mu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sl + cin_tile * 2 + 1, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     // ---- ticket: the last workgroup of this batch element merges every slot ------------------------------------------------
-    __threadfence();
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the slot stores above are acknowledged at device scope ...
+    __syncthreads();                                       // ... for every wave of this workgroup, before its ticket is drawn
     unsigned* counter = reinterpret_cast<unsigned*>(a.in_ws) + b;
     if (threadIdx.x == 0) {
         const unsigned total = (unsigned)(a.npatch * a.nct);
-        const unsigned old = atomicAdd(counter, 1u);
+        const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         reinterpret_cast<unsigned*>(lds)[0] = (old == total - 1) ? 1u : 0u;
     }
     __syncthreads();
     if (reinterpret_cast<unsigned*>(lds)[0] == 0u) return;
-    __threadfence();                                       // acquire: the other workgroups' slots
     const int tiles_per_par = C / 32;                      // C % 32 == 0 is checked by the launcher when statistics are requested
     // one thread per (parity, channel): its npatch slots in patch order (the loads do not depend on the running merge, so they
     // are unrolled and in flight together — one thread walking all 4 * npatch slots of a channel serialised ~100 memory round trips
     // at the tail of the launch: +35 us); then the four parities of a channel in parity order, through LDS
     for (int item = threadIdx.x; item < 4 * C; item += 64 * ROWS) {
         const int par = item / C, c = item - par * C;
-        const float2_t* sl = reinterpret_cast<const float2_t*>(slots + (size_t)(par * tiles_per_par + (c >> 5)) * a.npatch * 64) + (c & 31);
+        const float* sl = slots + (size_t)(par * tiles_per_par + (c >> 5)) * a.npatch * 64 + (c & 31) * 2;
         float n = 0.f, mu = 0.f, q = 0.f;
         int yy = 0, xx = 0;
 #pragma unroll 8
         for (int p = 0; p < a.npatch; ++p) {
-            const float2_t s2 = sl[(size_t)p * 32];
+            // device-coherent loads (they must not be served from this XCD's L2)
+            const float s_mu = __hip_atomic_load(sl + (size_t)p * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float s_q = __hip_atomic_load(sl + (size_t)p * 64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const float ni = (float)(min(ROWS, a.H - yy) * min(32, a.W - xx));
-            const float tot = n + ni, f = ni / tot, dlt = s2[0] - mu;
+            const float tot = n + ni, f = ni / tot, dlt = s_mu - mu;
             mu += dlt * f;
-            q += s2[1] + dlt * dlt * n * f;
+            q += s_q + dlt * dlt * n * f;
             n = tot;
             xx += 32;
             if (xx >= a.W) { xx = 0; yy += ROWS; }
@@ -832,7 +853,7 @@ int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
     a.out16 = reinterpret_cast<_Float16*>(d->out16); a.out16_groups = d->out16_groups; a.out16_goff = d->out16_group_offset;
     a.out32 = d->out32; a.out_ctot = d->out_ctot; a.out_coff = d->out_coff;
     a.out16b = reinterpret_cast<_Float16*>(d->out16b); a.out16b_groups = d->out16b_groups; a.out16_split = d->out16_split;
-    a.tap_w = d->tap_weights; a.tap_out = d->tap_out; a.tap_nout = d->tap_nout; a.tap_ntile = d->tap_tiles;
+    a.tap_w = d->tap_weights; a.tap_out = d->tap_out; a.tap_nout = d->tap_nout; a.tap_ntile = d->tap_tiles; a.tap_unscale = d->tap_unscale;
     if (a.tap_out) {
         if (d->epilogue != TCS_EPI_LINEAR || stride != 1 || !a.tap_w || a.tap_nout < 1 || a.tap_nout > 2 || a.tap_ntile < 1 ||
             a.tap_ntile > (d->Cout + 31) / 32) return TCS_EINVAL;

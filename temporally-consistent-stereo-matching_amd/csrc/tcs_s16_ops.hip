@@ -255,6 +255,7 @@ __global__ __launch_bounds__(256) void k_propagate_s16(const float* __restrict__
 // as the fp32 gradient, and the candidate stencil of update.py:259-289 runs from LDS.
 #define PT_T 16
 #define PT_S (PT_T + 2)
+template <int NT>
 __device__ __forceinline__ float taps_at_s16ops(const float* __restrict__ tp, int ntile, int nplanes, int o9, int gy, int gx, int H, int W) {
     const size_t HW = (size_t)H * W;
     float acc = 0.f;
@@ -264,12 +265,21 @@ __device__ __forceinline__ float taps_at_s16ops(const float* __restrict__ tp, in
         const bool in = qy >= 0 && qy < H && qx >= 0 && qx < W;
         const int q = min(max(qy, 0), H - 1) * W + min(max(qx, 0), W - 1);
         float s = 0.f;
-        for (int k = 0; k < ntile; ++k) s += tp[((size_t)k * nplanes + o9 + t) * HW + q];
+        if (NT > 0) {                                      // all NT loads of a tap in flight together (tcs_stencil.hip: taps_at)
+            float ld[NT > 0 ? NT : 1];
+#pragma unroll
+            for (int k = 0; k < NT; ++k) ld[k] = tp[((size_t)k * nplanes + o9 + t) * HW + q];
+#pragma unroll
+            for (int k = 0; k < NT; ++k) s += ld[k];
+        } else {
+            for (int k = 0; k < ntile; ++k) s += tp[((size_t)k * nplanes + o9 + t) * HW + q];
+        }
         acc += in ? s : 0.f;
     }
     return acc;
 }
 
+template <int NT>
 __global__ __launch_bounds__(256) void k_taps_propagate_s16(const float* __restrict__ taps, int ntile, const float* __restrict__ bias,
                                                              const float* __restrict__ g5, float post_scale, const float* __restrict__ disp,
                                                              int H, int W, float* __restrict__ grad_out, float* __restrict__ cand9,
@@ -285,7 +295,7 @@ __global__ __launch_bounds__(256) void k_taps_propagate_s16(const float* __restr
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
             // same order of additions as k_taps_sum (tcs_stencil.hip): bit-equal to the materialised gradient
-            const float v = ((taps_at_s16ops(tp, ntile, 18, o * 9, gy, gx, H, W) + (bias ? bias[o] : 0.f)) + g5[((size_t)b * 2 + o) * HW + q]) * post_scale;
+            const float v = ((taps_at_s16ops<NT>(tp, ntile, 18, o * 9, gy, gx, H, W) + (bias ? bias[o] : 0.f)) + g5[((size_t)b * 2 + o) * HW + q]) * post_scale;
             sg[o][e] = v;
             if (own && grad_out) grad_out[((size_t)b * 2 + o) * HW + q] = v;
         }
@@ -406,7 +416,8 @@ int tcs_propagate_disparity_s16(const float* grad, const float* disp, int B, int
 int tcs_taps_propagate_s16(const float* taps, int ntile, const float* bias2, const float* g5, float post_scale, const float* disp, int B, int H,
                            int W, float* grad_out, float* cand9, void* out16, int out_groups, tcs_stream_t stream) {
     if (!taps || !g5 || !disp || !out16 || ntile <= 0 || out_groups < 4 || B <= 0 || B > 65535 || H <= 0 || W <= 0) return TCS_EINVAL;
-    hipLaunchKernelGGL(k_taps_propagate_s16, dim3(tcs_cdiv(W, PT_T), tcs_cdiv(H, PT_T), B), dim3(256), 0, tcs_stream(stream), taps, ntile, bias2,
+    auto kern = ntile == 4 ? k_taps_propagate_s16<4> : (ntile == 8 ? k_taps_propagate_s16<8> : k_taps_propagate_s16<0>);
+    hipLaunchKernelGGL(kern, dim3(tcs_cdiv(W, PT_T), tcs_cdiv(H, PT_T), B), dim3(256), 0, tcs_stream(stream), taps, ntile, bias2,
                        g5, post_scale, disp, H, W, grad_out, cand9, reinterpret_cast<_Float16*>(out16), out_groups);
     return tcs_launch_status();
 }

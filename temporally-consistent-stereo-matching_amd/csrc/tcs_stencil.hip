@@ -248,6 +248,9 @@ __global__ __launch_bounds__(256) void k_avgpool3s2(const float* __restrict__ x,
 // in a fixed order (tile-major inside a tap: results do not depend on scheduling) at q = p + d(t) inside the image.  Three consumers:
 // the plain sum (API paths), the flow-step / gradient stencils of an iteration, and DispRefine's candidate stencil.
 // =====================================================================================================================
+// NT = number of tiles when known at compile time (the 9 * NT loads are then all in flight together; with a run-time loop every load
+// waited for the previous one: 72 serial round trips per element), 0 = run-time `ntile`
+template <int NT>
 __device__ __forceinline__ float taps_at(const float* __restrict__ tp /* [ntile][nout*9][HW] of this batch element */, int ntile, int nplanes,
                                          int o9, int gy, int gx, int H, int W) {
     const size_t HW = (size_t)H * W;
@@ -258,13 +261,22 @@ __device__ __forceinline__ float taps_at(const float* __restrict__ tp /* [ntile]
         const bool in = qy >= 0 && qy < H && qx >= 0 && qx < W;
         const int q = min(max(qy, 0), H - 1) * W + min(max(qx, 0), W - 1);
         float s = 0.f;
-        for (int k = 0; k < ntile; ++k) s += tp[((size_t)k * nplanes + o9 + t) * HW + q];
+        if (NT > 0) {
+            float ld[NT > 0 ? NT : 1];
+#pragma unroll
+            for (int k = 0; k < NT; ++k) ld[k] = tp[((size_t)k * nplanes + o9 + t) * HW + q];
+#pragma unroll
+            for (int k = 0; k < NT; ++k) s += ld[k];
+        } else {
+            for (int k = 0; k < ntile; ++k) s += tp[((size_t)k * nplanes + o9 + t) * HW + q];
+        }
         acc += in ? s : 0.f;
     }
     return acc;
 }
 
 // out[b][o][p] = (addend[b][o][p] + bias[o] + taps) * scale
+template <int NT>
 __global__ __launch_bounds__(256) void k_taps_sum(const float* __restrict__ taps, int ntile, int nout, const float* __restrict__ bias,
                                                   const float* __restrict__ addend, float scale, int H, int W, float* __restrict__ out) {
     const int b = blockIdx.y, HW = H * W;
@@ -273,7 +285,7 @@ __global__ __launch_bounds__(256) void k_taps_sum(const float* __restrict__ taps
     const int y = p / W, x = p - y * W;
     const float* tp = taps + (size_t)b * ntile * nout * 9 * HW;
     for (int o = 0; o < nout; ++o) {
-        float v = taps_at(tp, ntile, nout * 9, o * 9, y, x, H, W) + (bias ? bias[o] : 0.f);
+        float v = taps_at<NT>(tp, ntile, nout * 9, o * 9, y, x, H, W) + (bias ? bias[o] : 0.f);
         if (addend) v += addend[((size_t)b * nout + o) * HW + p];
         out[((size_t)b * nout + o) * HW + p] = v * scale;
     }
@@ -285,6 +297,7 @@ __global__ __launch_bounds__(256) void k_taps_sum(const float* __restrict__ taps
 // run from LDS.  Also emits delta itself (nullable) for callers that want FlowHead's output as a tensor.
 #define FT_T 16
 #define FT_S (FT_T + 4)
+template <int NT>
 __global__ __launch_bounds__(256) void k_flow_taps_step_grads(const float* __restrict__ coords1, const float* __restrict__ taps, int ntile,
                                                               const float* __restrict__ bias, int H, int W, float scale,
                                                               float* __restrict__ disp_q, float* __restrict__ grad, float* __restrict__ cands,
@@ -298,7 +311,7 @@ __global__ __launch_bounds__(256) void k_flow_taps_step_grads(const float* __res
     for (int e = threadIdx.x; e < FT_S * FT_S; e += 256) {
         const int ey = e / FT_S, ex = e - ey * FT_S;
         const int gy = min(max(ty0 + ey - 2, 0), H - 1), gx = min(max(tx0 + ex - 2, 0), W - 1);
-        const float dl = taps_at(tp, ntile, 9, 0, gy, gx, H, W) + bs;
+        const float dl = taps_at<NT>(tp, ntile, 9, 0, gy, gx, H, W) + bs;
         sd[e] = (float)gx - (c1[gy * W + gx] + dl);
         if (delta_out && ey >= 2 && ey < FT_T + 2 && ex >= 2 && ex < FT_T + 2 && ty0 + ey - 2 < H && tx0 + ex - 2 < W)
             delta_out[(size_t)b * HW + gy * W + gx] = dl;
@@ -342,34 +355,49 @@ __global__ __launch_bounds__(256) void k_flow_taps_step_grads(const float* __res
     }
 }
 
-// [nout][C][3][3] fp32 -> the producer's per-lane order: tw[tile][half][o*9 + t][r], channel = 32*tile + 4*half + (r&3) + 8*(r>>2)
-// (register r of a 32x32 accumulator tile, csrc/tcs_conv_s16.hip), zero beyond C
-__global__ __launch_bounds__(256) void k_pack_tap_weights(const float* __restrict__ w, int nout, int C, int ntile, float* __restrict__ packed) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= ntile * 2 * nout * 9 * 16) return;
-    const int r = i & 15, ot = (i >> 4) % (nout * 9), half = ((i >> 4) / (nout * 9)) & 1, tile = (i >> 4) / (nout * 9) / 2;
-    const int c = 32 * tile + 4 * half + (r & 3) + 8 * (r >> 2), o = ot / 9, t = ot - o * 9;
-    packed[i] = c < C ? w[((size_t)o * C + c) * 9 + t] : 0.f;
+// [nout][C][3][3] fp32 * scale -> A fragments of v_mfma_f32_32x32x16_f16, (hi, lo) split, for the product
+// P[o*9 + t][pixel] = sum_c w[o][c][t] * y[c][pixel] taken 32 channels (two k-steps) at a time from a producer's accumulator registers:
+// unit ((kstep * 2 + part) * 64 + lane), lane (m = l & 31: row o*9 + t, rows >= 9*nout zero; hh = l >> 5), element j = channel
+// kstep*16 + 8*(j>>2) + 4*hh + (j&3) — the order in which accumulator registers 8s .. 8s+7 of a 32-channel tile hold channels (the
+// accumulator-order k-steps of k_pack_weight_frags, tcs_s16_ops.hip).
+typedef _Float16 tap_half8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void k_pack_tap_weights(const float* __restrict__ w, int nout, int C, int nk, float scale, uint4* __restrict__ packed) {
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= nk * 128) return;
+    const int lane = u & 63, part = (u >> 6) & 1, ks = u >> 7;
+    const int m = lane & 31, hh = lane >> 5, o = m / 9, t = m - o * 9;
+    tap_half8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = ks * 16 + 8 * (j >> 2) + 4 * hh + (j & 3);
+        float xw = (m < 9 * nout && c < C) ? w[((size_t)o * C + c) * 9 + t] * scale : 0.f;
+        xw = __builtin_amdgcn_fmed3f(xw, -65504.f, 65504.f);
+        const _Float16 hi = (_Float16)xw, lo = (_Float16)(xw - (float)hi);
+        v[j] = part ? lo : hi;
+    }
+    packed[u] = *reinterpret_cast<uint4*>(&v);
 }
 
 extern "C" {
 
 size_t tcs_tap_weights_floats(int nout, int C) {
     if (nout < 1 || nout > 2 || C <= 0) return 0;
-    return (size_t)((C + 31) / 32) * 2 * nout * 9 * 16;
+    return (size_t)((C + 31) / 32) * 2 * 128 * 4;          // two 16-channel k-steps per tile x (hi, lo) x 64 lanes x 16 bytes
 }
 
-int tcs_pack_tap_weights(const float* w_oihw, int nout, int C, float* packed, tcs_stream_t stream) {
-    if (!w_oihw || !packed || nout < 1 || nout > 2 || C <= 0) return TCS_EINVAL;
-    const int ntile = (C + 31) / 32, n = ntile * 2 * nout * 9 * 16;
-    hipLaunchKernelGGL(k_pack_tap_weights, dim3((n + 255) / 256), dim3(256), 0, tcs_stream(stream), w_oihw, nout, C, ntile, packed);
+int tcs_pack_tap_weights(const float* w_oihw, int nout, int C, int scale_log2, float* packed, tcs_stream_t stream) {
+    if (!w_oihw || !packed || nout < 1 || nout > 2 || C <= 0 || scale_log2 < -60 || scale_log2 > 60) return TCS_EINVAL;
+    const int nk = ((C + 31) / 32) * 2, n = nk * 128;
+    hipLaunchKernelGGL(k_pack_tap_weights, dim3((n + 255) / 256), dim3(256), 0, tcs_stream(stream), w_oihw, nout, C, nk, ldexpf(1.0f, scale_log2),
+                       reinterpret_cast<uint4*>(packed));
     return tcs_launch_status();
 }
 
 int tcs_taps_sum(const float* taps, int ntile, int nout, const float* bias, const float* addend, float scale, int B, int H, int W, float* out,
                  tcs_stream_t stream) {
     if (!taps || !out || ntile <= 0 || nout < 1 || nout > 2 || B <= 0 || B > 65535 || H <= 0 || W <= 0) return TCS_EINVAL;
-    hipLaunchKernelGGL(k_taps_sum, dim3(tcs_cdiv((long long)H * W, 256), B), dim3(256), 0, tcs_stream(stream), taps, ntile, nout, bias, addend,
+    auto kern = ntile == 8 ? k_taps_sum<8> : (ntile == 4 ? k_taps_sum<4> : k_taps_sum<0>);
+    hipLaunchKernelGGL(kern, dim3(tcs_cdiv((long long)H * W, 256), B), dim3(256), 0, tcs_stream(stream), taps, ntile, nout, bias, addend,
                        scale, H, W, out);
     return tcs_launch_status();
 }
@@ -377,7 +405,8 @@ int tcs_taps_sum(const float* taps, int ntile, int nout, const float* bias, cons
 int tcs_flow_taps_step_grads(const float* coords1, const float* taps, int ntile, const float* bias, int B, int H, int W, float scale,
                              float* disp_q, float* grad, float* cands, float* delta_out, tcs_stream_t stream) {
     if (!coords1 || !taps || !disp_q || !grad || !cands || ntile <= 0 || B <= 0 || B > 65535 || H <= 0 || W <= 0) return TCS_EINVAL;
-    hipLaunchKernelGGL(k_flow_taps_step_grads, dim3(tcs_cdiv(W, FT_T), tcs_cdiv(H, FT_T), B), dim3(256), 0, tcs_stream(stream), coords1, taps,
+    auto kern = ntile == 8 ? k_flow_taps_step_grads<8> : (ntile == 4 ? k_flow_taps_step_grads<4> : k_flow_taps_step_grads<0>);
+    hipLaunchKernelGGL(kern, dim3(tcs_cdiv(W, FT_T), tcs_cdiv(H, FT_T), B), dim3(256), 0, tcs_stream(stream), coords1, taps,
                        ntile, bias, H, W, scale, disp_q, grad, cands, delta_out);
     return tcs_launch_status();
 }

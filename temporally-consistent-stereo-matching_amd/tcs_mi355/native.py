@@ -56,7 +56,7 @@ class ConvS16Desc(C.Structure):
         ("blend_coords1", c_fp), ("blend_flow_x", c_fp), ("blend_flow16", c_fp), ("blend_flow16_groups", c_int), ("blend_flow16_channel", c_int),
         ("out16b", c_fp), ("out16b_groups", c_int), ("out16_split", c_int),
         ("in_stats", c_fp), ("in_eps", c_f),
-        ("tap_weights", c_fp), ("tap_out", c_fp), ("tap_nout", c_int), ("tap_tiles", c_int),
+        ("tap_weights", c_fp), ("tap_out", c_fp), ("tap_nout", c_int), ("tap_tiles", c_int), ("tap_unscale", c_f),
     ]
 
 
@@ -111,7 +111,7 @@ SIGNATURES = {
     "tcs_deconv_in_stats_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
     "tcs_instance_norm_apply_s16": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_int, c_fp, c_int, c_fp, c_int, c_fp]),
     "tcs_tap_weights_floats": (c_sz, [c_int, c_int]),
-    "tcs_pack_tap_weights": (c_int, [c_fp, c_int, c_int, c_fp, c_fp]),
+    "tcs_pack_tap_weights": (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_fp]),
     "tcs_taps_sum": (c_int, [c_fp, c_int, c_int, c_fp, c_fp, c_f, c_int, c_int, c_int, c_fp, c_fp]),
     "tcs_flow_taps_step_grads": (c_int, [c_fp, c_fp, c_int, c_fp, c_int, c_int, c_int, c_f, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "tcs_taps_propagate_s16": (c_int, [c_fp, c_int, c_fp, c_fp, c_f, c_fp, c_int, c_int, c_int, c_fp, c_fp, c_fp, c_int, c_fp]),

@@ -161,7 +161,7 @@ def _out_grid(s: S16, stride: int):
 def conv2d(pc: PackedConv, srcs: Sequence[S16], act: str = "none", addend: Optional[torch.Tensor] = None, post_scale: float = 1.0,
            out16: Optional[S16] = None, out16_group_offset: int = 0, out32: Optional[torch.Tensor] = None, out_coff: int = 0,
            stride: int = 1, want32: bool = False, tile_cfg: int = 0, addend16: Optional[S16] = None, addend_ctot: int = 0,
-           out16b: Optional[S16] = None, out16_split: int = 0, taps: Optional["Taps"] = None, tap_weights: Optional[torch.Tensor] = None):
+           out16b: Optional[S16] = None, out16_split: int = 0, taps: Optional["Taps"] = None, tap_weights: Optional["FragWeights"] = None):
     """act(conv(cat(srcs)) + bias + addend) * post_scale -> S16 (`out16`, allocated when neither output is given)
     and/or fp32 NCHW (`out32`, or allocated when want32).  Returns (out16, out32).  `addend_ctot` > Cout: `addend` is a
     channel slice of a [B, addend_ctot, Ho, Wo] tensor (pass the sliced view).  `out16b`: output channels from `out16_split`
@@ -195,9 +195,10 @@ def conv2d(pc: PackedConv, srcs: Sequence[S16], act: str = "none", addend: Optio
     if taps is not None:
         if tap_weights is None or tuple(taps.data.shape) != (d.B, taps.ntile, 9 * taps.nout, Ho, Wo):
             raise ValueError("conv2d: `taps` needs `tap_weights` and a [B, ntile, 9*nout, H, W] buffer")
-        if tap_weights.numel() < nv.lib().tcs_tap_weights_floats(taps.nout, 32 * taps.ntile):
+        if tap_weights.data.numel() < nv.lib().tcs_tap_weights_floats(taps.nout, 32 * taps.ntile):
             raise ValueError("conv2d: `tap_weights` too small")
-        d.tap_weights, d.tap_out, d.tap_nout, d.tap_tiles = nv.ptr(tap_weights, "tap_weights"), nv.ptr(taps.data, "taps"), taps.nout, taps.ntile
+        d.tap_weights, d.tap_out, d.tap_nout, d.tap_tiles = nv.ptr(tap_weights.data, "tap_weights"), nv.ptr(taps.data, "taps"), taps.nout, taps.ntile
+        d.tap_unscale = float(tap_weights.unscale)
     if out32 is not None:
         d.out32, d.out_ctot, d.out_coff = nv.ptr(out32, "out32"), int(out32.shape[1]), int(out_coff)
     d.tile_cfg = int(tile_cfg)
@@ -361,15 +362,19 @@ class Taps:
     bias: Optional[torch.Tensor] = None
 
 
-def pack_taps(weight: torch.Tensor) -> torch.Tensor:
-    """[nout, C, 3, 3] weights of the folded convolution -> the producer's per-lane order (tcs_pack_tap_weights)."""
+def pack_taps(weight: torch.Tensor) -> "FragWeights":
+    """[nout, C, 3, 3] weights of the folded convolution -> fp16-split MFMA fragments in the producer's accumulator order
+    (tcs_pack_tap_weights); `.unscale` undoes the power-of-two pre-scale."""
     nout, C_ = int(weight.shape[0]), int(weight.shape[1])
     if tuple(weight.shape[2:]) != (3, 3) or nout not in (1, 2):
         raise ValueError("pack_taps: a 3x3 convolution with 1 or 2 output channels")
     w = weight.detach().float().contiguous()
+    import math
+    wmax = float(w.abs().max())
+    s_log2 = 0 if wmax == 0.0 else max(-40, min(40, int(12 - math.floor(math.log2(wmax)))))
     out = torch.empty(nv.lib().tcs_tap_weights_floats(nout, C_), dtype=torch.float32, device=w.device)
-    nv.check(nv.lib().tcs_pack_tap_weights(nv.ptr(w, "weight"), nout, C_, nv.ptr(out), nv.stream()), "tcs_pack_tap_weights")
-    return out
+    nv.check(nv.lib().tcs_pack_tap_weights(nv.ptr(w, "weight"), nout, C_, s_log2, nv.ptr(out), nv.stream()), "tcs_pack_tap_weights")
+    return FragWeights(out, torch.zeros(0, device=w.device), 2.0 ** (-s_log2))
 
 
 def taps_sum(t: Taps, addend: Optional[torch.Tensor] = None, scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
