@@ -76,8 +76,10 @@ struct S16Args {
 // (co0 already includes the lane half's +4).  S16 stores: the 4 registers 4q..4q+3 are 4 consecutive channels of group
 // (co0>>3)+q -> one 8-byte store per {hi, lo}.
 // ---------------------------------------------------------------------------------------------------------------------
+// `st`: this lane's pixel is real (its stores happen).  False only in LINEAR launches with tap partials, where EVERY lane runs the
+// epilogue on a clamped (valid) pixel because the fold is an MFMA: the matrix instruction takes its weight rows from all 64 lanes.
 template <int EPI>
-__device__ __forceinline__ void s16_epilogue_tile(const S16Args& a, int b, int co0, int py, int px, const f32x16& acc) {
+__device__ __forceinline__ void s16_epilogue_tile(const S16Args& a, int b, int co0, int py, int px, const f32x16& acc, bool st = true) {
     const int H = a.H, W = a.W;
     const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
     const int Hp = H + 2, Wp = W + 2;
@@ -129,7 +131,7 @@ __device__ __forceinline__ void s16_epilogue_tile(const S16Args& a, int b, int c
         if (a.out32) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (ok[r]) a.out32[((size_t)b * a.out_ctot + a.out_coff + cc[r]) * HW + pix] = v[r];
+                if (ok[r] && st) a.out32[((size_t)b * a.out_ctot + a.out_coff + cc[r]) * HW + pix] = v[r];
         }
         if (taps_here) {
             // tap partials (tcs_stencil.hip): P[tile][o*9 + t][pixel] = sum over this tile's 32 channels of w2[o][c][t] * v[c] — a 32 (rows
@@ -156,10 +158,10 @@ __device__ __forceinline__ void s16_epilogue_tile(const S16Args& a, int b, int c
 #pragma unroll
             for (int r = 0; r < 16; ++r) {                 // row of register r: (co0 & 4) + (r&3) + 8*(r>>2)
                 const int ot = (co0 & 4) + (r & 3) + 8 * (r >> 2);
-                if (ot < np) tp[(size_t)ot * HW] = pa[r] * a.tap_unscale;
+                if (ot < np && st) tp[(size_t)ot * HW] = pa[r] * a.tap_unscale;
             }
         }
-        if (a.out16 || (a.out16b && co0 >= a.out16_split)) {
+        if (st && (a.out16 || (a.out16b && co0 >= a.out16_split))) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int g = (co0 >> 3) + q, c_first = co0 + 8 * q;  // 4 consecutive channels c_first .. c_first + 3
@@ -479,16 +481,22 @@ __device__ unsigned long long tcs_s16_stamps[4 * 8192];
 #define S16_ABL_COMPUTE true
 #endif
 
-template <int KS, int MT, int ROWS, int KSTEPS, int NSTAGE, int STRIDE, int EPI, int RS = 0>
-__global__ __launch_bounds__(64 * ROWS) void k_conv_s16(S16Args a) {
+// RPW ("rows per wave") = 2: a wave owns TWO output rows, i.e. every weight fragment it fetches feeds two activation fragments.  With
+// one row per wave the 32-channel tile reads 4 operand fragments (1 KiB each) per 3 MFMAs: 4 SIMDs x 32 LDS clocks per 96 matrix clocks =
+// 133 % of the LDS port — the K loop is LDS-bandwidth bound (the measured 1.45 PFLOP/s ceiling).  Two rows per wave
+// read 6 fragments per 6 MFMAs (100 %), two rows x 64 channels 8 per 12 (67 %).  The block is ROWS / RPW waves; LDS per block is unchanged.
+template <int KS, int MT, int ROWS, int KSTEPS, int NSTAGE, int STRIDE, int EPI, int RS = 0, int RPW = 1>
+__global__ __launch_bounds__(64 * ROWS / RPW) void k_conv_s16(S16Args a) {
     static_assert(!RS || (KS == 3 && STRIDE == 1), "row split is for 3x3 stride-1 convolutions");
+    static_assert(ROWS % RPW == 0 && (RPW == 1 || (!RS && EPI != TCS_EPI_DECONV2X && EPI != TCS_EPI_BLEND9)), "rows per wave");
+    constexpr int NW = ROWS / RPW;                                  // waves per block
     constexpr int HALO = KS / 2, TAPS = KS * KS, TS = RS ? KS : TAPS;                       // TS: taps per stage
     constexpr int IH = RS ? ROWS : STRIDE * ROWS + KS - STRIDE, IW = STRIDE * 32 + KS - STRIDE, IN_CH = IH * IW;
     constexpr int IN_UNITS = KSTEPS * 4 * IN_CH;                    // sub-tiles [kstep][lane half][hi|lo][IH][IW]
     constexpr int NPI = (IN_UNITS + 63) / 64, NPW = KSTEPS * TS * MT * 2, NP = NPI + NPW;
-    constexpr int PPW = (NP + ROWS - 1) / ROWS;                     // DMA pieces per wave per stage
+    constexpr int PPW = (NP + NW - 1) / NW;                         // DMA pieces per wave per stage
     constexpr int STAGE_BYTES = NP * 1024, W_OFF = NPI * 1024;
-    constexpr int NSTEP = KSTEPS * TS, R = 2 + 2 * MT;              // operand reads per (k-step, tap)
+    constexpr int NSTEP = KSTEPS * TS, R = 2 * RPW + 2 * MT;        // operand reads per (k-step, tap)
     static_assert(R <= 15, "lgkmcnt field");
     static_assert(STAGE_BYTES <= 65536, "ds_read immediate offsets are 16 bits");
 
@@ -507,7 +515,7 @@ __global__ __launch_bounds__(64 * ROWS) void k_conv_s16(S16Args a) {
     unsigned voff[PPW];
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
-        const int p = min(wave + j * ROWS, NP - 1);                 // surplus slots repeat the last piece (same data, same place)
+        const int p = min(wave + j * NW, NP - 1);                   // surplus slots repeat the last piece (same data, same place)
         if (p < NPI) {
             const int u = min(p * 64 + lane, IN_UNITS - 1);
             const int sub = u / IN_CH, pos = u - sub * IN_CH;
@@ -545,28 +553,30 @@ __global__ __launch_bounds__(64 * ROWS) void k_conv_s16(S16Args a) {
         const unsigned dst0_ = lds_base + (unsigned)(BUF) * STAGE_BYTES;                                              \
         asm volatile("s_nop 4" ::: "memory");       /* v_readfirstlane-written SGPRs -> VMEM base: wait states */        \
         _Pragma("unroll") for (int j = 0; j < PPW; ++j) {                                                             \
-            const int p_ = min(wave + j * ROWS, NP - 1);                                                              \
+            const int p_ = min(wave + j * NW, NP - 1);                                                                \
             const char* base_ = p_ < NPI ? in_ptr_ : w_ptr_;                                                          \
             if (S16_ABL_DMA(p_ < NPI)) S16_DMA(voff[j], dst0_ + (unsigned)p_ * 1024u, base_)                          \
         }                                                                                                             \
     }
 
-    f32x16 acc[MT];
+    f32x16 acc[MT * RPW];                                           // [m * RPW + row]
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MT * RPW; ++m)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
 
     // operand fetch addresses inside a stage buffer
-    const unsigned addr_b0 = lds_base + (unsigned)((half * 2 * IN_CH + STRIDE * wave * IW + STRIDE * l31) * 16);
+    const unsigned addr_b0 = lds_base + (unsigned)((half * 2 * IN_CH + STRIDE * wave * RPW * IW + STRIDE * l31) * 16);
     const unsigned addr_a0 = lds_base + (unsigned)(W_OFF + lane * 16);
-    struct Frag { half8 b_hi, b_lo, a_hi[MT], a_lo[MT]; };
+    struct Frag { half8 b_hi[RPW], b_lo[RPW], a_hi[MT], a_lo[MT]; };
 #define S16_DSREAD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "i"(OFF) : "memory")
 #define S16_FETCH(F, STEP)                                                                                            \
     {                                                                                                                 \
         const int kk_ = (STEP) / TS, t_ = (STEP) % TS, dy_ = RS ? 0 : t_ / KS, dx_ = t_ % KS;  /* constants after unrolling */ \
-        S16_DSREAD(F.b_hi, addr_b, ((kk_ * 4 + 0) * IN_CH + dy_ * IW + dx_) * 16);                                    \
-        S16_DSREAD(F.b_lo, addr_b, ((kk_ * 4 + 1) * IN_CH + dy_ * IW + dx_) * 16);                                    \
+        _Pragma("unroll") for (int j = 0; j < RPW; ++j) {                                                             \
+            S16_DSREAD(F.b_hi[j], addr_b, ((kk_ * 4 + 0) * IN_CH + (dy_ + STRIDE * j) * IW + dx_) * 16);              \
+            S16_DSREAD(F.b_lo[j], addr_b, ((kk_ * 4 + 1) * IN_CH + (dy_ + STRIDE * j) * IW + dx_) * 16);              \
+        }                                                                                                             \
         _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                              \
             S16_DSREAD(F.a_hi[m], addr_a, (((kk_ * TS + t_) * MT + m) * 2 + 0) * 1024);                               \
             S16_DSREAD(F.a_lo[m], addr_a, (((kk_ * TS + t_) * MT + m) * 2 + 1) * 1024);                               \
@@ -575,9 +585,11 @@ __global__ __launch_bounds__(64 * ROWS) void k_conv_s16(S16Args a) {
 #define S16_WAIT_LGKM(N) { asm volatile("s_waitcnt lgkmcnt(%0)" :: "i"(N) : "memory"); __builtin_amdgcn_sched_barrier(0); }
 #define S16_MMA(F)                                                                                                    \
     _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                                  \
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_lo[m], F.b_hi, acc[m], 0, 0, 0);                          \
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_hi[m], F.b_lo, acc[m], 0, 0, 0);                          \
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_hi[m], F.b_hi, acc[m], 0, 0, 0);                          \
+        _Pragma("unroll") for (int j = 0; j < RPW; ++j) {                                                             \
+            acc[m * RPW + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_lo[m], F.b_hi[j], acc[m * RPW + j], 0, 0, 0); \
+            acc[m * RPW + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_hi[m], F.b_lo[j], acc[m * RPW + j], 0, 0, 0); \
+            acc[m * RPW + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a_hi[m], F.b_hi[j], acc[m * RPW + j], 0, 0, 0); \
+        }                                                                                                             \
     }
 
     // ---- prologue: every buffer is free, so NSTAGE stages go in flight at once ------------------------------------------
@@ -628,10 +640,19 @@ __global__ __launch_bounds__(64 * ROWS) void k_conv_s16(S16Args a) {
 #undef S16_MMA
     S16_STAMP(2)
 
-    const int px = x0 + l31, py = y0 + wave;
-    if (px < a.W && py < a.H) {
+    const int px = x0 + l31, py = y0 + wave * RPW;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) s16_epilogue_tile<EPI>(a, b, (ct * MT + m) * 32 + 4 * half, py, px, acc[m]);
+    for (int j = 0; j < RPW; ++j) {
+        if (EPI == TCS_EPI_LINEAR && a.tap_out != nullptr) {
+            // tap partials: all 64 lanes run the epilogue (on clamped pixels; only real pixels store) — see s16_epilogue_tile
+            const bool st = px < a.W && py + j < a.H;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                s16_epilogue_tile<EPI>(a, b, (ct * MT + m) * 32 + 4 * half, min(py + j, a.H - 1), min(px, a.W - 1), acc[m * RPW + j], st);
+        } else if (px < a.W && py + j < a.H) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) s16_epilogue_tile<EPI>(a, b, (ct * MT + m) * 32 + 4 * half, py + j, px, acc[m * RPW + j]);
+        }
     }
     if constexpr (EPI == TCS_EPI_DECONV2X) {
         if (a.in_ws) {
@@ -697,13 +718,13 @@ __global__ __launch_bounds__(256) void k_s16_to_f32(const _Float16* __restrict__
 // ---------------------------------------------------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------------------------------------------------
-template <int KS, int MT, int ROWS, int KSTEPS, int NSTAGE, int STRIDE, int EPI, int RS = 0>
+template <int KS, int MT, int ROWS, int KSTEPS, int NSTAGE, int STRIDE, int EPI, int RS = 0, int RPW = 1>
 static int launch_s16(S16Args& a, hipStream_t s) {
     constexpr int IH = RS ? ROWS : STRIDE * ROWS + KS - STRIDE, IW = STRIDE * 32 + KS - STRIDE, TS = RS ? KS : KS * KS;
     constexpr int NPI = (KSTEPS * 4 * IH * IW + 63) / 64, NP = NPI + KSTEPS * TS * MT * 2;
     constexpr size_t lds = (size_t)NSTAGE * NP * 1024;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = k_conv_s16<KS, MT, ROWS, KSTEPS, NSTAGE, STRIDE, EPI, RS>;
+    auto kern = k_conv_s16<KS, MT, ROWS, KSTEPS, NSTAGE, STRIDE, EPI, RS, RPW>;
     (void)hipGetLastError();                                        // a stale error of an earlier runtime call is not ours
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -713,18 +734,26 @@ static int launch_s16(S16Args& a, hipStream_t s) {
     a.nct = a.nct32 / MT;
     a.npatch = a.npx * tcs_cdiv(a.H, ROWS);
     if (a.csplit > 0 && a.nct % a.csplit != 0) a.csplit = 1;
-    hipLaunchKernelGGL(kern, dim3(a.npatch * a.nct, a.B), dim3(64 * ROWS), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(a.npatch * a.nct, a.B), dim3(64 * ROWS / RPW), lds, s, a);
     return tcs_launch_status();
 }
 
 // tile configuration: cfg = CSPLIT*100000 + RS*10000 + MT*1000 + ROWS*100 + KSTEPS*10 + NSTAGE (0 = heuristic; CSPLIT: see
-// s16_block_tile); unknown combinations -> EUNSUPPORTED
+// s16_block_tile; RS = 1: row split, RS = 2: two rows per wave); unknown combinations -> EUNSUPPORTED
 template <int KS, int STRIDE, int EPI>
 static int launch_s16_cfg(S16Args& a, int cfg, hipStream_t s) {
 #define S16_CASE(MT_, ROWS_, KST_, NST_) \
     case (MT_ * 1000 + ROWS_ * 100 + KST_ * 10 + NST_): return launch_s16<KS, MT_, ROWS_, KST_, NST_, STRIDE, EPI>(a, s);
 #define S16_CASE_RS(MT_, ROWS_, KST_, NST_) \
     case (10000 + MT_ * 1000 + ROWS_ * 100 + KST_ * 10 + NST_): return launch_s16<KS, MT_, ROWS_, KST_, NST_, STRIDE, EPI, 1>(a, s);
+#define S16_CASE_RPW2(MT_, ROWS_, KST_, NST_) \
+    case (20000 + MT_ * 1000 + ROWS_ * 100 + KST_ * 10 + NST_): return launch_s16<KS, MT_, ROWS_, KST_, NST_, STRIDE, EPI, 0, 2>(a, s);
+    if constexpr (KS == 3 && STRIDE == 1 && (EPI == TCS_EPI_LINEAR || EPI == TCS_EPI_GRU_ZR || EPI == TCS_EPI_GRU_Q)) {
+        switch (cfg) {
+            S16_CASE_RPW2(1, 8, 1, 2) S16_CASE_RPW2(2, 8, 1, 2) S16_CASE_RPW2(1, 4, 1, 2) S16_CASE_RPW2(1, 4, 1, 1) S16_CASE_RPW2(2, 4, 1, 2)
+            default: break;
+        }
+    }
     if constexpr (KS == 3 && STRIDE == 1) {
         switch (cfg) {
             S16_CASE(1, 4, 1, 1) S16_CASE(2, 4, 1, 1) S16_CASE(1, 8, 1, 1)
@@ -754,6 +783,7 @@ static int launch_s16_cfg(S16Args& a, int cfg, hipStream_t s) {
     }
 #undef S16_CASE
 #undef S16_CASE_RS
+#undef S16_CASE_RPW2
 }
 
 // Tile choice by grid size, from the layer sweep of tools/bench_conv_s16.py on MI355X (gpurun_out/r2_s16_c.log):

@@ -82,7 +82,8 @@ def test_conv2d_s16_vs_torch(dev, cfg):
     # +100000*CSPLIT block -> XCD mapping; 64-channel tiles (MT = 2) need an even number of 32-channel tiles
     if cfg["k"] == 3 and stride == 1:
         tiles += [1411, 1412, 1413, 1811, 1512, 101812, 201412]
-        tiles += [2411, 2412, 2413, 2512, 102812, 12412, 12413] if cfg["cout"] % 64 == 0 else []
+        tiles += [21812, 21412, 21411, 121812]                          # two rows per wave (RS digit 2)
+        tiles += [2411, 2412, 2413, 2512, 102812, 12412, 12413, 22812, 22412, 122812] if cfg["cout"] % 64 == 0 else []
     elif cfg["k"] == 1 and stride == 1:
         ksteps = [(c + 15) // 16 for c in cfg["cins"]]
         tiles += [1412]

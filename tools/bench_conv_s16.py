@@ -3,7 +3,7 @@
 on-the-fly split) on the refinement loop's layer shapes (GPU box).  For every shape and tile configuration: max abs difference
 to the old kernel's output (both contract the same fp16 halves, so they agree to fp32 summation order) and us per launch from
 a HIP-graph replay of a burst of launches timed with HIP events.
-usage: bench_conv_s16.py [only-substring] ; env CFGS=1413,2413,... restricts the tile configurations, BATCH=n sets the batch."""
+usage: bench_conv_s16.py [substring[,substring...]] ; env CFGS=1413,2413,... restricts the tile configurations, BATCH=n sets the batch."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -65,7 +65,7 @@ def timed(run, n=100, reps=3):
 
 
 for name, cins, cout, k, H, W, epi, stride in SHAPES:
-    if only and only not in name:
+    if only and not any(tok in name for tok in only.split(",")):
         continue
     cin = sum(cins)
     xs = [torch.randn(NB, c, H, W, generator=gen).to(dev) for c in cins]
