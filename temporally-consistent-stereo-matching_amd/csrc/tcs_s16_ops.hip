@@ -488,23 +488,27 @@ __device__ __forceinline__ void hu_frag_from_acc(const float* v8, half8& hi, hal
         HU_LDA(DH[t + 1], base_, 2048);                                                                           \
         HU_LDA(DL[t + 1], base_, 3072);                                                                           \
     }
+// HU_DEPTH k-steps of fragments in flight: one k-step is 3*NT MFMAs = 12 x 32 clocks = ~180 ns of matrix work per wave, an L2 hit is
+// ~600 ns, and a wave runs alone on its SIMD — with two k-steps in flight (round 2) every k-step waited ~400 ns for its weights
+// (30 us for 7 us of MFMAs).  The ring index is a compile-time constant after unrolling.
+#define HU_DEPTH 4
+#define HU_WAIT_NEWER(NEWER, NT)                                                                                  \
+    {                                                                                                             \
+        if ((NEWER) >= 3) HU_WAITV(3 * 2 * NT) else if ((NEWER) == 2) HU_WAITV(2 * 2 * NT)                        \
+        else if ((NEWER) == 1) HU_WAITV(2 * NT) else HU_WAITV(0)                                                  \
+    }
 #define HU_GEMM(ACC, NT, NK, WBASE, NTT, T0, BFRAG)                                                               \
     {                                                                                                             \
-        half8 a0h[NT], a0l[NT], a1h[NT], a1l[NT];                                                                 \
-        HU_ISSUE(a0h, a0l, NT, WBASE, NTT, T0, 0)                                                                 \
-        _Pragma("unroll") for (int s = 0; s < NK; s += 2) {                                                       \
-            if (s + 1 < NK) { HU_ISSUE(a1h, a1l, NT, WBASE, NTT, T0, s + 1) HU_WAITV(2 * NT) } else HU_WAITV(0)   \
-            {                                                                                                     \
-                half8 bh_, bl_;                                                                                   \
-                BFRAG(s, bh_, bl_)                                                                                \
-                _Pragma("unroll") for (int t = 0; t < NT; ++t) { HU_MMA3(ACC[t], a0h[t], a0l[t], bh_, bl_) }      \
-            }                                                                                                     \
-            if (s + 1 < NK) {                                                                                     \
-                if (s + 2 < NK) { HU_ISSUE(a0h, a0l, NT, WBASE, NTT, T0, s + 2) HU_WAITV(2 * NT) } else HU_WAITV(0) \
-                half8 bh_, bl_;                                                                                   \
-                BFRAG(s + 1, bh_, bl_)                                                                            \
-                _Pragma("unroll") for (int t = 0; t < NT; ++t) { HU_MMA3(ACC[t], a1h[t], a1l[t], bh_, bl_) }      \
-            }                                                                                                     \
+        static_assert((HU_DEPTH - 1) * 2 * NT <= 63, "vmcnt field");                                              \
+        half8 ah_[HU_DEPTH][NT], al_[HU_DEPTH][NT];                                                               \
+        _Pragma("unroll") for (int d = 0; d < HU_DEPTH - 1; ++d)                                                  \
+            if (d < NK) { HU_ISSUE(ah_[d], al_[d], NT, WBASE, NTT, T0, d) }                                       \
+        _Pragma("unroll") for (int s = 0; s < NK; ++s) {                                                          \
+            if (s + HU_DEPTH - 1 < NK) { HU_ISSUE(ah_[(s + HU_DEPTH - 1) % HU_DEPTH], al_[(s + HU_DEPTH - 1) % HU_DEPTH], NT, WBASE, NTT, T0, s + HU_DEPTH - 1) } \
+            HU_WAIT_NEWER((NK - 1 - s) < (HU_DEPTH - 1) ? (NK - 1 - s) : (HU_DEPTH - 1), NT)                      \
+            half8 bh_, bl_;                                                                                       \
+            BFRAG(s, bh_, bl_)                                                                                    \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) { HU_MMA3(ACC[t], ah_[s % HU_DEPTH][t], al_[s % HU_DEPTH][t], bh_, bl_) } \
         }                                                                                                         \
     }
 
