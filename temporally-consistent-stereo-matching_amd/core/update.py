@@ -141,6 +141,8 @@ def conv16(pool, conv, srcs, act="none", addend=None, post_scale=1.0, out=None, 
     tc = 0
     if "t2" in _X and conv.kernel_size[0] == 3 and stride == 1 and a.H * a.W >= 10000:
         tc = 101812                      # A/B: two-stage 8-row tiles on every 1/4-scale 3x3 layer
+    if "rpw" in _X and conv.kernel_size[0] == 3 and stride == 1 and a.H * a.W >= 10000 and conv.out_channels <= 128:
+        tc = 121812                      # A/B: two rows per wave on the 1/4-scale 3x3 layers with <= 128 outputs
     if want32:
         return s16.conv2d(pc, srcs, act=act, addend=addend, post_scale=post_scale, want32=True, stride=stride, tile_cfg=tc,
                           addend16=addend16)[1]
@@ -168,7 +170,7 @@ def up_block16(pool, block: Conv2x_IN, x: s16.S16, rem: s16.S16) -> s16.S16:
     dc = block.conv1.conv
     y = pool.get((id(dc), "o"), x.B, dc.out_channels, 2 * x.H, 2 * x.W, x.device)
     stats = None
-    if "noinfuse" not in _X and s16.deconv_in_stats_ok(x.B, dc.out_channels):
+    if "noinfuse" not in _X and s16.deconv_in_stats_ok(x.B, dc.out_channels, x.H, x.W):
         # the transposed convolution reduces the InstanceNorm statistics of its own output (last-workgroup merge): no statistics
         # launch between it and the apply kernel
         stats = pool.get32((id(dc), "in_stats"), (s16.nv.lib().tcs_deconv_in_stats_bytes(x.B, dc.out_channels, x.H, x.W) // 4,), x.device,
@@ -568,7 +570,7 @@ class DispGradPredictor(nn.Module):
         def stem_c():
             return conv16(pool, self.conv_grad_candidate_stem[2], [conv32to16(pool, self.conv_grad_candidate_stem[0], cands, act="relu")])
 
-        x4_grad, x4_cand = fork_join([stem_g, stem_c], site="stems")
+        x4_cand, x4_grad = fork_join([stem_c, stem_g], site="stems")       # the longer chain (fp32-MFMA candidate stem) on the origin stream
         x4 = feat(self.conv_4_4[0], [x4_grad, x4_cand], pre[0])
         x8 = conv16(pool, self.conv_4_8[0], [x4], act="relu")                    # 3x3 stride 2
         x8 = feat(self.conv_8_8[0], [x8], pre[1])

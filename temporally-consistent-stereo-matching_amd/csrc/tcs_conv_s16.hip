@@ -301,6 +301,20 @@ __device__ __forceinline__ void s16_epilogue_tile(const S16Args& a, int b, int c
 // first launch), then finals [B][C][2], then slots [B][nct32][npatch][32][2].
 // ---------------------------------------------------------------------------------------------------------------------
 #define S16_IN_WS_HEAD 16
+#define S16_IN_MAXLD 12             // 16-byte loads per thread of the last workgroup's slot fetch
+// do the slots of one batch element (+ the merge scratch) fit the last workgroup's fetch and the kernel's LDS?
+static inline bool s16_in_stats_fits(int nct32, int npatch, int C, int threads, size_t lds_bytes) {
+    const size_t nfl = (size_t)nct32 * npatch * 64;
+    return nfl <= (size_t)threads * 4 * S16_IN_MAXLD && (8 + nfl + 12 * (size_t)C) * sizeof(float) <= lds_bytes;
+}
+// ... for a 3x3 stride-1 tile configuration MT*1000 + ROWS*100 + KSTEPS*10 + NSTAGE on an [H, W] input grid with 4*C output channels
+static inline bool s16_cfg_in_stats_ok(int cfg, int C, int H, int W) {
+    const int mt = (cfg / 1000) % 10, rows = (cfg / 100) % 10, kst = (cfg / 10) % 10, nst = cfg % 10;
+    if (mt < 1 || rows < 1 || kst != 1 || nst < 1) return false;
+    const int np = ((rows + 2) * 34 * 4 + 63) / 64 + 9 * mt * 2;                     // 1 KiB DMA pieces per stage (k_conv_s16: NP)
+    const int npatch = ((W + 31) / 32) * ((H + rows - 1) / rows);
+    return s16_in_stats_fits(4 * C / 32, npatch, C, 64 * rows, (size_t)nst * np * 1024);
+}
 template <int MT, int ROWS>
 __device__ __forceinline__ void s16_deconv_stats(const S16Args& a, int b, int ct, int patch, int py, int px, int wave, int lane,
                                                  const f32x16* acc, float* lds /* >= max(ROWS * 64, 8 + 12 * C) floats, free to use */) {
@@ -384,19 +398,37 @@ __device__ __forceinline__ void s16_deconv_stats(const S16Args& a, int b, int ct
     __syncthreads();
     if (reinterpret_cast<unsigned*>(lds)[0] == 0u) return;
     const int tiles_per_par = C / 32;                      // C % 32 == 0 is checked by the launcher when statistics are requested
-    // one thread per (parity, channel): its npatch slots in patch order (the loads do not depend on the running merge, so they
-    // are unrolled and in flight together — one thread walking all 4 * npatch slots of a channel serialised ~100 memory round trips
-    // at the tail of the launch: +35 us); then the four parities of a channel in parity order, through LDS
-    for (int item = threadIdx.x; item < 4 * C; item += 64 * ROWS) {
+    // All slots of this batch element come into LDS with one batch of device-coherent (sc1: not served from this XCD's L2) 16-byte
+    // loads, every load in flight at once — the slots live at the memory side, ~1.5 us away, and a first version that walked them with
+    // a load -> merge loop per thread paid that latency 24 times (+12 us per launch).  The launcher guarantees that they fit
+    // (s16_in_stats_fits).  Then one thread per (parity, channel) merges its npatch slots in patch order, and the four parities of a
+    // channel are merged in parity order: a fixed order, whoever came last.
+    constexpr int NTH = 64 * ROWS;
+    const int nfl = nslot_b * 64;
+    float* cp = lds + 8;
+    float* mo = cp + nfl;
+    {
+        float4_t r[S16_IN_MAXLD];
+#pragma unroll
+        for (int k = 0; k < S16_IN_MAXLD; ++k) {
+            const float* src = slots + min((int)(threadIdx.x + k * NTH) * 4, nfl - 4);
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r[k]) : "v"(src) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < S16_IN_MAXLD; ++k) {
+            const int i = (int)(threadIdx.x + k * NTH) * 4;
+            if (i < nfl) *reinterpret_cast<float4_t*>(cp + i) = r[k];
+        }
+    }
+    __syncthreads();
+    for (int item = threadIdx.x; item < 4 * C; item += NTH) {
         const int par = item / C, c = item - par * C;
-        const float* sl = slots + (size_t)(par * tiles_per_par + (c >> 5)) * a.npatch * 64 + (c & 31) * 2;
+        const float* sl = cp + (size_t)(par * tiles_per_par + (c >> 5)) * a.npatch * 64 + (c & 31) * 2;
         float n = 0.f, mu = 0.f, q = 0.f;
         int yy = 0, xx = 0;
-#pragma unroll 8
         for (int p = 0; p < a.npatch; ++p) {
-            // device-coherent loads (they must not be served from this XCD's L2)
-            const float s_mu = __hip_atomic_load(sl + (size_t)p * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float s_q = __hip_atomic_load(sl + (size_t)p * 64 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float s_mu = sl[p * 64], s_q = sl[p * 64 + 1];
             const float ni = (float)(min(ROWS, a.H - yy) * min(32, a.W - xx));
             const float tot = n + ni, f = ni / tot, dlt = s_mu - mu;
             mu += dlt * f;
@@ -405,16 +437,16 @@ __device__ __forceinline__ void s16_deconv_stats(const S16Args& a, int b, int ct
             xx += 32;
             if (xx >= a.W) { xx = 0; yy += ROWS; }
         }
-        lds[8 + item * 3 + 0] = n;
-        lds[8 + item * 3 + 1] = mu;
-        lds[8 + item * 3 + 2] = q;
+        mo[item * 3 + 0] = n;
+        mo[item * 3 + 1] = mu;
+        mo[item * 3 + 2] = q;
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 64 * ROWS) {
+    for (int c = threadIdx.x; c < C; c += NTH) {
         float n = 0.f, mu = 0.f, q = 0.f;
 #pragma unroll
         for (int par = 0; par < 4; ++par) {
-            const float ni = lds[8 + (par * C + c) * 3], mi = lds[8 + (par * C + c) * 3 + 1], qi = lds[8 + (par * C + c) * 3 + 2];
+            const float ni = mo[(par * C + c) * 3], mi = mo[(par * C + c) * 3 + 1], qi = mo[(par * C + c) * 3 + 2];
             const float tot = n + ni, f = ni / tot, dlt = mi - mu;
             mu += dlt * f;
             q += qi + dlt * dlt * n * f;
@@ -733,6 +765,7 @@ static int launch_s16(S16Args& a, hipStream_t s) {
     a.npx = tcs_cdiv(a.W, 32);
     a.nct = a.nct32 / MT;
     a.npatch = a.npx * tcs_cdiv(a.H, ROWS);
+    if (a.in_ws && !s16_in_stats_fits(a.nct32, a.npatch, a.hidden, 64 * ROWS / RPW, lds)) return TCS_EUNSUPPORTED;   // (checked before, s16_cfg_in_stats_ok)
     if (a.csplit > 0 && a.nct % a.csplit != 0) a.csplit = 1;
     hipLaunchKernelGGL(kern, dim3(a.npatch * a.nct, a.B), dim3(64 * ROWS / RPW), lds, s, a);
     return tcs_launch_status();
@@ -816,6 +849,9 @@ size_t tcs_deconv_in_stats_bytes(int B, int C, int H, int W) {
     if (B <= 0 || B > S16_IN_WS_HEAD || C <= 0 || C % 32 != 0 || H <= 0 || W <= 0) return 0;
     // the smallest patch any tile configuration uses is 4 rows x 32 columns of the INPUT grid
     const size_t npatch = (size_t)tcs_cdiv(W, 32) * tcs_cdiv(H, 4), nct32 = (size_t)4 * C / 32;
+    // 0 = not supported at this size (the last workgroup's fetch is sized for the loop's up-blocks): neither the 4-row nor the 8-row
+    // two-stage tile can hold the slots; callers then use the two-launch tcs_instance_norm_s16
+    if (!s16_cfg_in_stats_ok(1412, C, H, W) && !s16_cfg_in_stats_ok(1812, C, H, W)) return 0;
     return (S16_IN_WS_HEAD + (size_t)B * C * 2 + (size_t)B * nct32 * npatch * 64) * sizeof(float);
 }
 
@@ -931,6 +967,12 @@ int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
         cfg = s16_heuristic(a, d->ksize, stride, kst);
         a.csplit = cfg / 100000;
         cfg %= 100000;
+    }
+    if (a.in_ws) {                                     // fused InstanceNorm statistics: the slots must fit the last workgroup's fetch
+        if (!s16_cfg_in_stats_ok(cfg, d->Cout / 4, d->H, d->W)) {
+            if (d->tile_cfg % 100000 != 0 || !s16_cfg_in_stats_ok(1812, d->Cout / 4, d->H, d->W)) return TCS_EUNSUPPORTED;
+            cfg = 1812;                                // the heuristic's tile does not, the 8-row two-stage tile does
+        }
     }
     if (a.nct32 % ((cfg / 1000) % 10) != 0) return TCS_EUNSUPPORTED;          // the cout tile must divide the packed tiles
 

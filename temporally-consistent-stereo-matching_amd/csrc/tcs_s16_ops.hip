@@ -253,7 +253,8 @@ __global__ __launch_bounds__(256) void k_propagate_s16(const float* __restrict__
 // gradient predictor never runs as a launch.  grad[o] = (g5[o] + bias[o] + taps[o]) * post_scale (core/update.py:213) is assembled for a
 // 16x16 pixel tile and its 1-pixel halo in LDS (clamped positions; the zero padding of update.py:277 is applied at use), written out
 // as the fp32 gradient, and the candidate stencil of update.py:259-289 runs from LDS.
-#define PT_T 16
+#define PT_T 16                     // tile: PT_T x PT_TY pixels; with the halo 18 x 10 = 180 elements, one per thread
+#define PT_TY 8
 #define PT_S (PT_T + 2)
 template <int NT>
 __device__ __forceinline__ float taps_at_s16ops(const float* __restrict__ tp, int ntile, int nplanes, int o9, int gy, int gx, int H, int W) {
@@ -284,14 +285,14 @@ __global__ __launch_bounds__(256) void k_taps_propagate_s16(const float* __restr
                                                              const float* __restrict__ g5, float post_scale, const float* __restrict__ disp,
                                                              int H, int W, float* __restrict__ grad_out, float* __restrict__ cand9,
                                                              _Float16* __restrict__ out16, int Go) {
-    __shared__ float sg[2][PT_S * PT_S];
+    __shared__ float sg[2][PT_S * (PT_TY + 2)];
     const int b = blockIdx.z, HW = H * W;
-    const int tx0 = blockIdx.x * PT_T, ty0 = blockIdx.y * PT_T;
+    const int tx0 = blockIdx.x * PT_T, ty0 = blockIdx.y * PT_TY;
     const float* tp = taps + (size_t)b * ntile * 18 * HW;
-    for (int e = threadIdx.x; e < PT_S * PT_S; e += 256) {
+    for (int e = threadIdx.x; e < PT_S * (PT_TY + 2); e += 256) {
         const int ey = e / PT_S, ex = e - ey * PT_S;
         const int gy = min(max(ty0 + ey - 1, 0), H - 1), gx = min(max(tx0 + ex - 1, 0), W - 1), q = gy * W + gx;
-        const bool own = ey >= 1 && ey <= PT_T && ex >= 1 && ex <= PT_T && ty0 + ey - 1 < H && tx0 + ex - 1 < W;
+        const bool own = ey >= 1 && ey <= PT_TY && ex >= 1 && ex <= PT_T && ty0 + ey - 1 < H && tx0 + ex - 1 < W;
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
             // same order of additions as k_taps_sum (tcs_stencil.hip): bit-equal to the materialised gradient
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(256) void k_taps_propagate_s16(const float* __restr
     __syncthreads();
     const int ly = threadIdx.x / PT_T, lx = threadIdx.x - ly * PT_T;
     const int y = ty0 + ly, x = tx0 + lx;
-    if (y >= H || x >= W) return;
+    if (ly >= PT_TY || y >= H || x >= W) return;
     const int p = y * W + x;
     const float* d = disp + (size_t)b * HW;
     const float gcx = sg[0][(ly + 1) * PT_S + lx + 1], gcy = sg[1][(ly + 1) * PT_S + lx + 1];
@@ -417,7 +418,7 @@ int tcs_taps_propagate_s16(const float* taps, int ntile, const float* bias2, con
                            int W, float* grad_out, float* cand9, void* out16, int out_groups, tcs_stream_t stream) {
     if (!taps || !g5 || !disp || !out16 || ntile <= 0 || out_groups < 4 || B <= 0 || B > 65535 || H <= 0 || W <= 0) return TCS_EINVAL;
     auto kern = ntile == 4 ? k_taps_propagate_s16<4> : (ntile == 8 ? k_taps_propagate_s16<8> : k_taps_propagate_s16<0>);
-    hipLaunchKernelGGL(kern, dim3(tcs_cdiv(W, PT_T), tcs_cdiv(H, PT_T), B), dim3(256), 0, tcs_stream(stream), taps, ntile, bias2,
+    hipLaunchKernelGGL(kern, dim3(tcs_cdiv(W, PT_T), tcs_cdiv(H, PT_TY), B), dim3(256), 0, tcs_stream(stream), taps, ntile, bias2,
                        g5, post_scale, disp, H, W, grad_out, cand9, reinterpret_cast<_Float16*>(out16), out_groups);
     return tcs_launch_status();
 }

@@ -295,31 +295,32 @@ __global__ __launch_bounds__(256) void k_taps_sum(const float* __restrict__ taps
 // 2-pixel halo is assembled once in LDS (positions outside the image hold the value of the clamped position: the replicate padding
 // of geo_utils.py:117; the zero padding of geo_utils.py:91 is applied where the candidates are formed), then the three stencils
 // run from LDS.  Also emits delta itself (nullable) for callers that want FlowHead's output as a tensor.
-#define FT_T 16
+#define FT_T 16                     // tile: FT_T x FT_TY pixels; with the halo (FT_T + 4) x (FT_TY + 4) = 240 elements, one per thread
+#define FT_TY 8
 #define FT_S (FT_T + 4)
 template <int NT>
 __global__ __launch_bounds__(256) void k_flow_taps_step_grads(const float* __restrict__ coords1, const float* __restrict__ taps, int ntile,
                                                               const float* __restrict__ bias, int H, int W, float scale,
                                                               float* __restrict__ disp_q, float* __restrict__ grad, float* __restrict__ cands,
                                                               float* __restrict__ delta_out) {
-    __shared__ float sd[FT_S * FT_S];
+    __shared__ float sd[FT_S * (FT_TY + 4)];
     const int b = blockIdx.z, HW = H * W;
-    const int tx0 = blockIdx.x * FT_T, ty0 = blockIdx.y * FT_T;
+    const int tx0 = blockIdx.x * FT_T, ty0 = blockIdx.y * FT_TY;
     const float* c1 = coords1 + (size_t)b * HW;
     const float* tp = taps + (size_t)b * ntile * 9 * HW;
     const float bs = bias ? bias[0] : 0.f;
-    for (int e = threadIdx.x; e < FT_S * FT_S; e += 256) {
+    for (int e = threadIdx.x; e < FT_S * (FT_TY + 4); e += 256) {
         const int ey = e / FT_S, ex = e - ey * FT_S;
         const int gy = min(max(ty0 + ey - 2, 0), H - 1), gx = min(max(tx0 + ex - 2, 0), W - 1);
         const float dl = taps_at<NT>(tp, ntile, 9, 0, gy, gx, H, W) + bs;
         sd[e] = (float)gx - (c1[gy * W + gx] + dl);
-        if (delta_out && ey >= 2 && ey < FT_T + 2 && ex >= 2 && ex < FT_T + 2 && ty0 + ey - 2 < H && tx0 + ex - 2 < W)
+        if (delta_out && ey >= 2 && ey < FT_TY + 2 && ex >= 2 && ex < FT_T + 2 && ty0 + ey - 2 < H && tx0 + ex - 2 < W)
             delta_out[(size_t)b * HW + gy * W + gx] = dl;
     }
     __syncthreads();
     const int ly = threadIdx.x / FT_T, lx = threadIdx.x - ly * FT_T;
     const int y = ty0 + ly, x = tx0 + lx;
-    if (y >= H || x >= W) return;
+    if (ly >= FT_TY || y >= H || x >= W) return;
     const int p = y * W + x;
 #define FT_D(DY, DX) sd[(ly + 2 + (DY)) * FT_S + (lx + 2 + (DX))]
     const float c = FT_D(0, 0);
@@ -406,7 +407,7 @@ int tcs_flow_taps_step_grads(const float* coords1, const float* taps, int ntile,
                              float* disp_q, float* grad, float* cands, float* delta_out, tcs_stream_t stream) {
     if (!coords1 || !taps || !disp_q || !grad || !cands || ntile <= 0 || B <= 0 || B > 65535 || H <= 0 || W <= 0) return TCS_EINVAL;
     auto kern = ntile == 8 ? k_flow_taps_step_grads<8> : (ntile == 4 ? k_flow_taps_step_grads<4> : k_flow_taps_step_grads<0>);
-    hipLaunchKernelGGL(kern, dim3(tcs_cdiv(W, FT_T), tcs_cdiv(H, FT_T), B), dim3(256), 0, tcs_stream(stream), coords1, taps,
+    hipLaunchKernelGGL(kern, dim3(tcs_cdiv(W, FT_T), tcs_cdiv(H, FT_TY), B), dim3(256), 0, tcs_stream(stream), coords1, taps,
                        ntile, bias, H, W, scale, disp_q, grad, cands, delta_out);
     return tcs_launch_status();
 }

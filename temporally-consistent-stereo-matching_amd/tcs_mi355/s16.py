@@ -206,9 +206,10 @@ def conv2d(pc: PackedConv, srcs: Sequence[S16], act: str = "none", addend: Optio
     return out16, out32
 
 
-def deconv_in_stats_ok(B: int, cout: int) -> bool:
-    """Can the transposed convolution compute the InstanceNorm statistics of its own output (tcs_conv_s16_desc.in_stats)?"""
-    return cout % 32 == 0 and B <= 16
+def deconv_in_stats_ok(B: int, cout: int, H: int, W: int) -> bool:
+    """Can the transposed convolution compute the InstanceNorm statistics of its own output (tcs_conv_s16_desc.in_stats) at this
+    size ([H, W] = its INPUT grid)?"""
+    return cout % 32 == 0 and B <= 16 and nv.lib().tcs_deconv_in_stats_bytes(int(B), int(cout), int(H), int(W)) > 0
 
 
 def deconv_in_stats_workspace(B: int, cout: int, H: int, W: int, device) -> torch.Tensor:

@@ -419,7 +419,11 @@ def test_deconv_fused_instance_norm_statistics(dev):
         ws = s16.deconv_in_stats_workspace(B, cout, H, W, dev)
         for rep in range(3):
             for tc in (0, 1412, 101812):
-                y = s16.deconv4x4s2(pc, [x16], in_stats=ws, tile_cfg=tc)
+                try:
+                    y = s16.deconv4x4s2(pc, [x16], in_stats=ws, tile_cfg=tc)
+                except RuntimeError as e:               # an explicitly requested tile whose slots exceed the last workgroup's fetch
+                    assert tc != 0 and "unsupported" in str(e), (cout, tc, e)
+                    continue
                 fin = ws[16:16 + B * cout * 2].view(B, cout, 2).cpu().double()
                 ys = y.float().cpu().double()
                 assert maxdiff(fin[..., 0], ys.mean((2, 3))) <= 1e-5, (cout, tc)
