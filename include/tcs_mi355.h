@@ -416,7 +416,7 @@ int tcs_softmax_blend_s16(const float* logits9, const float* cand, int cand_ctot
  * q = tanh(Wq.[r*h,x] + bq); h <- z*h + (1-z)*q, in place on the S16 hidden state (128 channels).  The three 1x1 weight
  * matrices are A-fragment images from tcs_pack_weight_frags: `natural_channels` leading input channels in S16 order (operands read
  * from an S16 tensor), the rest in accumulator order (operands handed over in registers by the preceding layer):
- * W2: natural 64; Wzr [256 x 192]: natural 128; Wq [128 x 192]: natural 0. */
+ * W2: natural 64; Wzr [256 x 192]: natural 0 (h is fetched in accumulator order too); Wq [128 x 192]: natural 0. */
 size_t tcs_weight_frags_bytes(int Cout, int Cin);
 int tcs_pack_weight_frags(const float* w_oi, int Cout, int Cin, int natural_channels, int scale_log2, void* packed, tcs_stream_t stream);
 int tcs_hidden_update_s16(void* h, int h_groups, const float* delta, const float* w1, const float* b1, const void* W2, const float* b2,

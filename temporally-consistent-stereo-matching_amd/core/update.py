@@ -143,6 +143,8 @@ def conv16(pool, conv, srcs, act="none", addend=None, post_scale=1.0, out=None, 
         tc = 101812                      # A/B: two-stage 8-row tiles on every 1/4-scale 3x3 layer
     if "rpw" in _X and conv.kernel_size[0] == 3 and stride == 1 and a.H * a.W >= 10000 and conv.out_channels <= 128:
         tc = 121812                      # A/B: two rows per wave on the 1/4-scale 3x3 layers with <= 128 outputs
+    if "norpw" in _X and conv.kernel_size[0] == 3 and stride == 1 and a.H * a.W >= 10000 and 96 <= conv.out_channels <= 128:
+        tc = 101411                      # A/B: round 2's tile where the heuristic now picks two rows per wave
     if want32:
         return s16.conv2d(pc, srcs, act=act, addend=addend, post_scale=post_scale, want32=True, stride=stride, tile_cfg=tc,
                           addend16=addend16)[1]
@@ -170,9 +172,11 @@ def up_block16(pool, block: Conv2x_IN, x: s16.S16, rem: s16.S16) -> s16.S16:
     dc = block.conv1.conv
     y = pool.get((id(dc), "o"), x.B, dc.out_channels, 2 * x.H, 2 * x.W, x.device)
     stats = None
-    if "noinfuse" not in _X and s16.deconv_in_stats_ok(x.B, dc.out_channels, x.H, x.W):
-        # the transposed convolution reduces the InstanceNorm statistics of its own output (last-workgroup merge): no statistics
-        # launch between it and the apply kernel
+    if "infuse" in _X and s16.deconv_in_stats_ok(x.B, dc.out_channels, x.H, x.W):
+        # OFF by default (A/B token "infuse"): the transposed convolution reduces the InstanceNorm statistics of its own output
+        # (last-workgroup merge), which saves the statistics launch — and costs as much: device-coherent slot stores, their
+        # acknowledgement, a ticket atomic and the last workgroup's fetch are ~7 us of serial latency at the tail of a 15-us
+        # launch.  Measured three times on one box each: +1.3, +-0.3, +0.1..0.5 ms per frame
         stats = pool.get32((id(dc), "in_stats"), (s16.nv.lib().tcs_deconv_in_stats_bytes(x.B, dc.out_channels, x.H, x.W) // 4,), x.device,
                            zero=True)
     s16.deconv4x4s2(packed_deconv(dc), [x], out16=y, in_stats=stats)
@@ -311,7 +315,7 @@ class HiddenstateUpdater(_GateCell):
             w1 = self.convs[0].weight.detach().float().reshape(64).contiguous()
             b1 = self.convs[0].bias.detach().float().contiguous()
             hit = (key, (w1, b1, s16.pack_frags(self.convs[2].weight, self.convs[2].bias, 64),
-                         s16.pack_frags(self.convzr.weight, self.convzr.bias, 128), s16.pack_frags(self.convq.weight, self.convq.bias, 0)))
+                         s16.pack_frags(self.convzr.weight, self.convzr.bias, 0), s16.pack_frags(self.convq.weight, self.convq.bias, 0)))
             self._tcs_frags = hit
         return hit[1]
 

@@ -824,7 +824,7 @@ static int launch_s16_cfg(S16Args& a, int cfg, hipStream_t s) {
 //  * smaller grids (1/8 scale with 128 outputs, 1/16 scale, transposed convs): 4-row patches, 32-channel tiles, two stages;
 //  * 1x1: two k-steps per stage; 64-channel tiles for Cout >= 256;
 //  * CSPLIT = 1 (all cout tiles of a patch on one XCD, s16_block_tile): 0-3 % on 3x3, 20-30 % on the 1x1 layers.
-static int s16_heuristic(const S16Args& a, int ksize, int stride, int kst1x1) {
+static int s16_heuristic(const S16Args& a, int ksize, int stride, int kst1x1, int epilogue) {
     if (ksize == 1 && stride == 2) return 1000 + 400 + kst1x1 * 10 + 2;
     if (ksize == 1) {
         const int mt = (a.nct32 % 2 == 0 && a.nct32 >= 8) ? 2 : 1;
@@ -837,6 +837,10 @@ static int s16_heuristic(const S16Args& a, int ksize, int stride, int kst1x1) {
         // patches with ONE 31 KiB stage, so that up to five workgroups per CU cover each other's fills (128->128: 25.4 -> 23.8 us,
         // 192->128: 33.4 -> 31.7 us, gru08.q 69.5 -> 58.7 us)
         if (a.nct32 >= 8 && a.nk >= 16) return 100000 + 1000 + 800 + 10 + 2;
+        // 128..192 -> 96..128 channels (context compress, fuse, w_head, encoder.conv): 8-row patches with TWO rows per wave (every weight
+        // fragment feeds two activation fragments): 31.4 -> 29.5 us (128 -> 128), 40.9 -> 38.1 us (192 -> 128) alone, -0.6 ms per frame
+        // together; narrower or shallower layers lose with it (64 -> 64: 12.3 -> 15.2 us), gru08 does not move
+        if (epilogue == TCS_EPI_LINEAR && a.nk >= 8 && a.nk <= 12 && a.nct32 >= 3 && a.nct32 <= 4) return 100000 + 20000 + 1000 + 800 + 10 + 2;
         return 100000 + 1000 + 400 + 10 + 1;
     }
     if (blocks8 >= 180) return 100000 + 1000 + 800 + 10 + 2;
@@ -964,7 +968,7 @@ int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
     if (a.out32 && d->epilogue == TCS_EPI_LINEAR && (d->out_coff < 0 || d->out_coff + d->Cout > d->out_ctot)) return TCS_EINVAL;
     hipStream_t s = tcs_stream(stream);
     if (!cfg) {
-        cfg = s16_heuristic(a, d->ksize, stride, kst);
+        cfg = s16_heuristic(a, d->ksize, stride, kst, d->epilogue);
         a.csplit = cfg / 100000;
         cfg %= 100000;
     }

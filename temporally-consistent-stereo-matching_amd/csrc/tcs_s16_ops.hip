@@ -443,9 +443,18 @@ int tcs_s16_set_channel(const float* x, int B, int H, int W, void* s16, int grou
 // Every layer is pixelwise, so a wave keeps its 32 pixels from the first layer to the last: an accumulator tile
 // (32 channels x 32 pixels, pixel on the lane) becomes the B operand of the next layer's MFMAs after bias + activation +
 // fp16 split, with no LDS round trip and no lane movement (registers 8s..8s+7 of a tile are k-step s; the weights of
-// such K ranges are packed in the matching permuted channel order by tcs_pack_weight_frags).  h comes straight from
-// the S16 tensor in operand form.  Weights are read as ready-made A fragments (1 KiB per wave-load, L2-resident).
-// Four launches (single-channel conv, 64->64, zr, q: 62 us per iteration) become one.
+// such K ranges are packed in the matching permuted channel order by tcs_pack_weight_frags).  h is fetched ONCE, in that same
+// accumulator order (8-byte half-units of the S16 tensor), and serves as B operand of the gates, as the factor of r*h and in the
+// final blend; z stays in registers.
+//
+// Weights (304 KB of A fragments per wave-pass) stream through LDS: the four waves of a workgroup share every fragment, and
+// one k-step of a four-tile pass is 8 KiB = 8 LDS-DMA instructions (global_load_lds_dwordx4, two per wave).  The 40 stages of the
+// four products (W2: 4 x 4 KiB; z, r, q: 12 x 8 KiB each) form ONE software pipeline, HU_D stages in flight across the products'
+// boundaries, so the weights of the next product arrive during the activation arithmetic of the current one:
+//     wait own pieces of stage g (counted vmcnt) -> s_barrier -> refill the buffer of stage g-1 with stage g+HU_D-1 -> 2*NT
+//     ds_read_b128 -> 3*NT MFMAs.
+// Round 2's version read the fragments per wave from L2 (310 KB per wave, 186 MB per launch through the L1s): 30 us alone,
+// 41-47 us inside the loop; deeper register prefetch changed nothing (the L1 fill rate, not latency, was the bound).
 // =====================================================================================================================
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -454,17 +463,12 @@ struct HuArgs {
     int h_groups;
     const float* delta;          // [B,1,H,W]
     const float* w1; const float* b1;            // convs[0]: [64] each
-    const uint4* W2; const float* b2;            // fragment-packed 64x64, natural K
-    const uint4* Wzr; const float* bzr;          // 256 x (128 natural | 64 permuted)
-    const uint4* Wq; const float* bq;            // 128 x (128 permuted | 64 permuted)
+    const uint4* W2; const float* b2;            // fragment-packed 64x64, natural K (layer 1 is produced in natural order)
+    const uint4* Wzr; const float* bzr;          // 256 x 192, accumulator-order K
+    const uint4* Wq; const float* bq;            // 128 x 192, accumulator-order K
     float us2, uszr, usq;                        // 2^-scale of the packed weights
     int B, H, W;
 };
-
-__device__ __forceinline__ half8 hu_ldA(const uint4* w, int idx) {   // idx in 16-byte units, already includes the lane
-    const uint4 v = w[idx];
-    return *reinterpret_cast<const half8*>(&v);
-}
 
 #define HU_MMA3(ACC, AHI, ALO, BHI, BLO)                                          \
     ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ALO, BHI, ACC, 0, 0, 0);        \
@@ -473,45 +477,6 @@ __device__ __forceinline__ half8 hu_ldA(const uint4* w, int idx) {   // idx in 1
 
 // accumulator registers 8*sub .. 8*sub+7 of a tile (already bias-added / activated, fp32) -> B fragment (hi, lo) of a k-step
 __device__ __forceinline__ void hu_frag_from_acc(const float* v8, half8& hi, half8& lo) { split8(v8, hi, lo); }
-
-// One MFMA K loop over NK k-steps for NT (even) output tiles T0 .. T0+NT-1 of a packed matrix with NTT tiles per k-step.
-// The A fragments are double-buffered in registers by INLINE-ASM loads with counted waits: the 2*NT loads of k-step s+1 are in
-// flight during the 3*NT MFMAs of k-step s.  (A wave runs alone on its SIMD here, so nothing else hides the L2 latency of
-// the weight fragments, and hipcc sinks compiler-visible loads next to their first use: load -> vmcnt(0) -> MFMA, 277 times.)
-// Two tiles share one SGPR base (the immediate offset field is 13 bits).  BFRAG(s, bh, bl) yields the B operand of k-step s.
-#define HU_LDA(DST, BASE, IMM) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(DST) : "v"(voffA), "s"(BASE), "i"(IMM) : "memory")
-#define HU_WAITV(N) { asm volatile("s_waitcnt vmcnt(%0)" :: "i"(N) : "memory"); __builtin_amdgcn_sched_barrier(0); }
-#define HU_ISSUE(DH, DL, NT, WBASE, NTT, T0, S)                                                                   \
-    _Pragma("unroll") for (int t = 0; t < NT; t += 2) {                                                           \
-        const char* base_ = uniform_ptr_ops(reinterpret_cast<const char*>(WBASE) + (size_t)(((S) * (NTT) + (T0) + t) * 2) * 1024); \
-        HU_LDA(DH[t], base_, 0);                                                                                  \
-        HU_LDA(DL[t], base_, 1024);                                                                               \
-        HU_LDA(DH[t + 1], base_, 2048);                                                                           \
-        HU_LDA(DL[t + 1], base_, 3072);                                                                           \
-    }
-// HU_DEPTH k-steps of fragments in flight: one k-step is 3*NT MFMAs = 12 x 32 clocks = ~180 ns of matrix work per wave, an L2 hit is
-// ~600 ns, and a wave runs alone on its SIMD — with two k-steps in flight (round 2) every k-step waited ~400 ns for its weights
-// (30 us for 7 us of MFMAs).  The ring index is a compile-time constant after unrolling.
-#define HU_DEPTH 4
-#define HU_WAIT_NEWER(NEWER, NT)                                                                                  \
-    {                                                                                                             \
-        if ((NEWER) >= 3) HU_WAITV(3 * 2 * NT) else if ((NEWER) == 2) HU_WAITV(2 * 2 * NT)                        \
-        else if ((NEWER) == 1) HU_WAITV(2 * NT) else HU_WAITV(0)                                                  \
-    }
-#define HU_GEMM(ACC, NT, NK, WBASE, NTT, T0, BFRAG)                                                               \
-    {                                                                                                             \
-        static_assert((HU_DEPTH - 1) * 2 * NT <= 63, "vmcnt field");                                              \
-        half8 ah_[HU_DEPTH][NT], al_[HU_DEPTH][NT];                                                               \
-        _Pragma("unroll") for (int d = 0; d < HU_DEPTH - 1; ++d)                                                  \
-            if (d < NK) { HU_ISSUE(ah_[d], al_[d], NT, WBASE, NTT, T0, d) }                                       \
-        _Pragma("unroll") for (int s = 0; s < NK; ++s) {                                                          \
-            if (s + HU_DEPTH - 1 < NK) { HU_ISSUE(ah_[(s + HU_DEPTH - 1) % HU_DEPTH], al_[(s + HU_DEPTH - 1) % HU_DEPTH], NT, WBASE, NTT, T0, s + HU_DEPTH - 1) } \
-            HU_WAIT_NEWER((NK - 1 - s) < (HU_DEPTH - 1) ? (NK - 1 - s) : (HU_DEPTH - 1), NT)                      \
-            half8 bh_, bl_;                                                                                       \
-            BFRAG(s, bh_, bl_)                                                                                    \
-            _Pragma("unroll") for (int t = 0; t < NT; ++t) { HU_MMA3(ACC[t], ah_[s % HU_DEPTH][t], al_[s % HU_DEPTH][t], bh_, bl_) } \
-        }                                                                                                         \
-    }
 
 __device__ __forceinline__ const char* uniform_ptr_ops(const char* p) {
     const unsigned long long u = reinterpret_cast<unsigned long long>(p);
@@ -545,8 +510,65 @@ __device__ __forceinline__ float hu_tanh(float v) {
 
 #define HU_WAVES 4
 #define HU_NBIAS (64 + 64 + 64 + 256 + 128)           // w1, b1, b2, bzr, bq
+#define HU_D 4                                        // weight stages in flight
+#define HU_STAGE_BYTES 8192
+#define HU_RING_OFF 4096                              // byte offset of the stage ring behind the bias table
+#define HU_NSTAGE 40                                  // W2: 0-3 (4 KiB), z: 4-15, r: 16-27, q: 28-39 (8 KiB each)
+#define HU_PIECES(G) ((G) < 4 ? 1 : ((G) < HU_NSTAGE ? 2 : 0))      // LDS-DMA instructions per wave and stage
+
+// LDS-DMA of one 1 KiB piece (as in tcs_conv_s16.hip): 64 lanes x 16 B from (wave-uniform base + per-lane byte offset) to LDS byte
+// address DST (wave-uniform, in M0) + lane * 16
+#define HU_DMA(VOFF, DST, BASE)                                                                                       \
+    {                                                                                                                 \
+        unsigned keep_;                                                                                               \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"  \
+                     : "=&s"(keep_) : "v"(VOFF), "s"(DST), "s"(BASE) : "memory");                                    \
+    }
+// stage G (a compile-time constant after unrolling) -> its 4 or 8 KiB of packed fragments; wave w copies piece w (and w + 4)
+#define HU_ISSUE(G)                                                                                                   \
+    {                                                                                                                 \
+        if ((G) < HU_NSTAGE) {                                                                                        \
+            const char* src_ = (G) < 4 ? wb2 + (size_t)(G) * 4096                                                     \
+                             : ((G) < 16 ? wbzr + (size_t)((G) - 4) * 16384                                           \
+                             : ((G) < 28 ? wbzr + (size_t)((G) - 16) * 16384 + 8192 : wbq + (size_t)((G) - 28) * 8192)); \
+            const char* base_ = uniform_ptr_ops(src_);                                                                \
+            const unsigned dst_ = lds_ring + (unsigned)((G) % HU_D) * HU_STAGE_BYTES + (unsigned)wave * 1024u;        \
+            asm volatile("s_nop 4" ::: "memory");                                                                     \
+            HU_DMA(voff0, dst_, base_)                                                                                \
+            if ((G) >= 4) HU_DMA(voff1, dst_ + 4096u, base_)                                                          \
+        }                                                                                                             \
+    }
+#define HU_WAITV_N(N)                                                                                                 \
+    {                                                                                                                 \
+        if ((N) >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                \
+        else if ((N) == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                           \
+        else if ((N) == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                           \
+        else if ((N) == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                                           \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
+    }
+#define HU_DSREAD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "i"(OFF) : "memory")
+// one product: NK k-steps starting at global stage G0, NT output tiles; BFRAG(s, bh, bl) yields the B operand of k-step s
+#define HU_GEMM(ACC, NT, NK, G0, BFRAG)                                                                               \
+    _Pragma("unroll") for (int s = 0; s < NK; ++s) {                                                                  \
+        /* own pieces of stage G0+s have landed; stages G0+s+1, G0+s+2 (issued earlier) may stay in flight */          \
+        HU_WAITV_N(HU_PIECES((G0) + s + 1) + HU_PIECES((G0) + s + 2))                                                 \
+        __builtin_amdgcn_s_barrier();               /* everyone's pieces landed; everyone is done with stage G0+s-1 */   \
+        HU_ISSUE((G0) + s + HU_D - 1)                                                                                 \
+        half8 ah_[NT], al_[NT];                                                                                       \
+        const unsigned ra_ = lds_ring + (unsigned)(((G0) + s) % HU_D) * HU_STAGE_BYTES + voff_lane;                   \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                              \
+            HU_DSREAD(ah_[t], ra_, (t * 2 + 0) * 1024);                                                               \
+            HU_DSREAD(al_[t], ra_, (t * 2 + 1) * 1024);                                                               \
+        }                                                                                                             \
+        half8 bh_, bl_;                                                                                               \
+        BFRAG(s, bh_, bl_)                                                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) { HU_MMA3(ACC[t], ah_[t], al_[t], bh_, bl_) }                  \
+    }
+
 __global__ __launch_bounds__(64 * HU_WAVES) void k_hidden_update_s16(HuArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float hu_lds[];            // [HU_NBIAS] biases, then z gates: [wave][64 regs][64 lanes]
+    extern __shared__ __attribute__((aligned(16))) float hu_lds[];            // [HU_NBIAS] biases | (at HU_RING_OFF) HU_D stage buffers
     const int lane = threadIdx.x & 63, l31 = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int npx = (a.W + 31) / 32;
@@ -556,26 +578,40 @@ __global__ __launch_bounds__(64 * HU_WAVES) void k_hidden_update_s16(HuArgs a) {
     const int yc = min(y, a.H - 1), xc = min(x, a.W - 1);                       // clamped: inactive lanes compute on a valid pixel
     const int Hp = a.H + 2, Wp = a.W + 2;
     const size_t plane = (size_t)Hp * Wp * 8;
-    float* zl = hu_lds + HU_NBIAS + (size_t)wave * 64 * 64 + lane;
-    const unsigned voffA = (unsigned)lane * 16u;
+    const unsigned lds_ring = __builtin_amdgcn_groupstaticsize() + HU_RING_OFF;
+    const unsigned voff_lane = (unsigned)lane * 16u;
+    const unsigned voff0 = (unsigned)wave * 1024u + voff_lane, voff1 = voff0 + 4096u;
+    const char* wb2 = reinterpret_cast<const char*>(a.W2);
+    const char* wbzr = reinterpret_cast<const char*>(a.Wzr);
+    const char* wbq = reinterpret_cast<const char*>(a.Wq);
+
+    // ---- the weight pipeline starts before anything else: stages 0 .. HU_D-2 ------------------------------------------------
+#pragma unroll
+    for (int g = 0; g < HU_D - 1; ++g) HU_ISSUE(g)
+
     // biases (and the single-channel first layer) through LDS: per-lane global loads of them inside the activation code
     // serialised on ~90 separate memory round trips
     for (int i = threadIdx.x; i < HU_NBIAS; i += 64 * HU_WAVES)
         hu_lds[i] = i < 64 ? a.w1[i] : (i < 128 ? a.b1[i - 64] : (i < 192 ? a.b2[i - 128] : (i < 448 ? a.bzr[i - 192] : a.bq[i - 448])));
     const float* s_w1 = hu_lds, *s_b1 = hu_lds + 64, *s_b2 = hu_lds + 128, *s_bzr = hu_lds + 192, *s_bq = hu_lds + 448;
 
-    // the 8 h fragments (B operands of the z|r layer: 128 channels in S16 order) are fetched once, up front
-    half8 hbh[8], hbl[8];
+    // h in accumulator order, as B fragments: k-step s (16 channels) = tile s>>1, registers 8(s&1) .. 8(s&1)+7 = groups
+    // 4(s>>1) + 2(s&1) + {0, 1}, slot 4*hh — two 8-byte half-units per plane
+    half8 hfh[8], hfl[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        const _Float16* u = a.h + s16_unit(b, a.h_groups, 2 * s + hh, 0, Hp, Wp, yc, xc);
-        hbh[s] = *reinterpret_cast<const half8*>(u);
-        hbl[s] = *reinterpret_cast<const half8*>(u + plane);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const _Float16* u = a.h + s16_unit(b, a.h_groups, 4 * (s >> 1) + 2 * (s & 1) + q, 0, Hp, Wp, yc, xc) + 4 * hh;
+            const half4 hi = *reinterpret_cast<const half4*>(u);
+            const half4 lo = *reinterpret_cast<const half4*>(u + plane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { hfh[s][4 * q + j] = hi[j]; hfl[s][4 * q + j] = lo[j]; }
+        }
     }
     // ---- layer 1 (VALU) straight into B-operand form: channel 16s + 8hh + j ------------------------------------------
     const float d = a.delta[((size_t)b * a.H + yc) * a.W + xc];
     __syncthreads();
-    HU_WAITV(0)              // the compiler-visible loads above have landed: from here on vmcnt is counted by hand
     half8 x1h[4], x1l[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -588,6 +624,8 @@ __global__ __launch_bounds__(64 * HU_WAVES) void k_hidden_update_s16(HuArgs a) {
         }
         split8(v, x1h[s], x1l[s]);
     }
+    // every compiler-visible global load above has been consumed (the compiler waited for it: its waits also cover the older DMA pieces);
+    // from here to the final stores the only vector-memory traffic is the weight pipeline, waited for by count
     // ---- layer 2: x = W2 . x1 + b2 -> fragments of 4 k-steps --------------------------------------------------------------
     half8 xh[4], xl[4];
     {
@@ -597,7 +635,7 @@ __global__ __launch_bounds__(64 * HU_WAVES) void k_hidden_update_s16(HuArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 #define HU_B_X1(S, BH, BL) { BH = x1h[(S) < 4 ? (S) : 0]; BL = x1l[(S) < 4 ? (S) : 0]; }
-        HU_GEMM(acc, 2, 4, a.W2, 2, 0, HU_B_X1)
+        HU_GEMM(acc, 2, 4, 0, HU_B_X1)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             float v[16];
@@ -607,70 +645,65 @@ __global__ __launch_bounds__(64 * HU_WAVES) void k_hidden_update_s16(HuArgs a) {
             hu_frag_from_acc(v + 8, xh[2 * t + 1], xl[2 * t + 1]);
         }
     }
-#define HU_B_HX(S, BH, BL) { if ((S) < 8) { BH = hbh[(S) < 8 ? (S) : 0]; BL = hbl[(S) < 8 ? (S) : 0]; } else { BH = xh[(S) >= 8 ? (S) - 8 : 0]; BL = xl[(S) >= 8 ? (S) - 8 : 0]; } }
-    // ---- z = sigmoid(Wzr[0:128] . [h, x] + bz): tiles 0-3 of the packed z|r matrix (8 tiles per k-step) -> LDS ----------
+#define HU_B_HX(S, BH, BL) { if ((S) < 8) { BH = hfh[(S) < 8 ? (S) : 0]; BL = hfl[(S) < 8 ? (S) : 0]; } else { BH = xh[(S) >= 8 ? (S) - 8 : 0]; BL = xl[(S) >= 8 ? (S) - 8 : 0]; } }
+    // ---- z = sigmoid(Wzr[0:128] . [h, x] + bz): tiles 0-3 of the packed z|r matrix; stays in registers ------------------------
+    f32x16 zz[4];
     {
         f32x16 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-        {
-            HU_GEMM(acc, 4, 12, a.Wzr, 8, 0, HU_B_HX)
+        HU_GEMM(acc, 4, 12, 4, HU_B_HX)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float pre = acc[t][i] * a.uszr + s_bzr[32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh];
-                    zl[(t * 16 + i) * 64] = hu_sigmoid(pre);
-                    acc[t][i] = 0.f;
-                }
-            }
-            // ---- r = sigmoid(Wzr[128:256] . [h, x] + br): tiles 4-7; r*h -> fragments of the q layer's first 8 k-steps ----
-            HU_GEMM(acc, 4, 12, a.Wzr, 8, 4, HU_B_HX)
-        }
-        half8 rhh[8], rhl[8];
+            for (int i = 0; i < 16; ++i) zz[t][i] = hu_sigmoid(acc[t][i] * a.uszr + s_bzr[32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh]);
+    }
+    // ---- r = sigmoid(Wzr[128:256] . [h, x] + br): tiles 4-7; r*h -> fragments of the q layer's first 8 k-steps -------------------
+    half8 rhh[8], rhl[8];
+    {
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        HU_GEMM(acc, 4, 12, 16, HU_B_HX)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             float v[16];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const _Float16* hp = a.h + s16_unit(b, a.h_groups, 4 * t + q, 0, Hp, Wp, yc, xc) + 4 * hh;
-                const half4 hi = *reinterpret_cast<const half4*>(hp);
-                const half4 lo = *reinterpret_cast<const half4*>(hp + plane);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int i = 4 * q + j;
-                    const float pre = acc[t][i] * a.uszr + s_bzr[128 + 32 * t + 8 * q + 4 * hh + j];
-                    v[i] = ((float)hi[j] + (float)lo[j]) * hu_sigmoid(pre);
-                }
+            for (int i = 0; i < 16; ++i) {
+                const float pre = acc[t][i] * a.uszr + s_bzr[128 + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh];
+                const float hv = (float)hfh[2 * t + (i >> 3)][i & 7] + (float)hfl[2 * t + (i >> 3)][i & 7];
+                v[i] = hv * hu_sigmoid(pre);
             }
             hu_frag_from_acc(v, rhh[2 * t], rhl[2 * t]);
             hu_frag_from_acc(v + 8, rhh[2 * t + 1], rhl[2 * t + 1]);
         }
-        HU_WAITV(0)          // (the h loads of the r*h products)
-        // ---- q = tanh(Wq . [r*h, x] + bq); h' = z*h + (1-z)*q ----------------------------------------------------------------
+    }
+    // ---- q = tanh(Wq . [r*h, x] + bq); h' = z*h + (1-z)*q ----------------------------------------------------------------
+    {
+        f32x16 acc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 #define HU_B_RHX(S, BH, BL) { if ((S) < 8) { BH = rhh[(S) < 8 ? (S) : 0]; BL = rhl[(S) < 8 ? (S) : 0]; } else { BH = xh[(S) >= 8 ? (S) - 8 : 0]; BL = xl[(S) >= 8 ? (S) - 8 : 0]; } }
-        HU_GEMM(acc, 4, 12, a.Wq, 4, 0, HU_B_RHX)
+        HU_GEMM(acc, 4, 12, 28, HU_B_RHX)
         if (!active) return;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 _Float16* hp = a.h + s16_unit(b, a.h_groups, 4 * t + q, 0, Hp, Wp, y, x) + 4 * hh;
-                const half4 hi = *reinterpret_cast<const half4*>(hp);
-                const half4 lo = *reinterpret_cast<const half4*>(hp + plane);
                 float v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int i = 4 * q + j;
                     const float qv = hu_tanh(acc[t][i] * a.usq + s_bq[32 * t + 8 * q + 4 * hh + j]);
-                    const float z = zl[(t * 16 + i) * 64], hv = (float)hi[j] + (float)lo[j];
-                    v[j] = z * hv + (1.f - z) * qv;
+                    const float hv = (float)hfh[2 * t + (i >> 3)][i & 7] + (float)hfl[2 * t + (i >> 3)][i & 7];
+                    v[j] = zz[t][i] * hv + (1.f - zz[t][i]) * qv;
                 }
                 s16_store4(hp, plane, v, 4);
             }
@@ -754,7 +787,7 @@ int tcs_hidden_update_s16(void* h, int h_groups, const float* delta, const float
     a.W2 = reinterpret_cast<const uint4*>(W2); a.b2 = b2; a.Wzr = reinterpret_cast<const uint4*>(Wzr); a.bzr = bzr;
     a.Wq = reinterpret_cast<const uint4*>(Wq); a.bq = bq; a.us2 = unscale2; a.uszr = unscale_zr; a.usq = unscale_q;
     a.B = B; a.H = H; a.W = W;
-    const size_t lds = ((size_t)HU_NBIAS + (size_t)HU_WAVES * 64 * 64) * sizeof(float);
+    const size_t lds = (size_t)HU_RING_OFF + (size_t)HU_D * HU_STAGE_BYTES;
     (void)hipGetLastError();
     hipLaunchKernelGGL(k_hidden_update_s16, dim3(tcs_cdiv(W, 32) * tcs_cdiv(H, HU_WAVES), B), dim3(64 * HU_WAVES), lds, tcs_stream(stream), a);
     return tcs_launch_status();

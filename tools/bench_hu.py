@@ -14,7 +14,7 @@ B = int(os.environ.get("BATCH", "1"))
 H, W = 120, 160
 h = s16.to_s16(torch.tanh(R(B, 128, H, W)))
 delta = R(B, 1, H, W)
-w = (R(64), R(64) * 0.1, s16.pack_frags(R(64, 64, 1, 1) * 0.15, R(64) * 0.1, 64), s16.pack_frags(R(256, 192, 1, 1) * 0.08, R(256) * 0.1, 128),
+w = (R(64), R(64) * 0.1, s16.pack_frags(R(64, 64, 1, 1) * 0.15, R(64) * 0.1, 64), s16.pack_frags(R(256, 192, 1, 1) * 0.08, R(256) * 0.1, 0),
      s16.pack_frags(R(128, 192, 1, 1) * 0.08, R(128) * 0.1, 0))
 run = lambda: s16.hidden_update(h, delta, *w)
 for _ in range(3):
