@@ -547,6 +547,27 @@ class DispGradPredictor(nn.Module):
         grad, ctx = self.run(pool, g5, cands, self.prepare(pool, c16))
         return grad, ctx.float()
 
+    def _stems_block_diagonal(self):
+        """(34 -> 96 fp32-MFMA, 96 -> 96 fp16-split) packed convolutions = conv_grad_stem and conv_grad_candidate_stem side by side:
+        output channels 0-31 see only the gradient inputs / hidden channels, 32-95 only the candidates'."""
+        g0, g2, c0, c2 = self.conv_grad_stem[0], self.conv_grad_stem[2], self.conv_grad_candidate_stem[0], self.conv_grad_candidate_stem[2]
+        key = tuple((m.weight.data_ptr(), m.weight._version, m.bias.data_ptr(), m.bias._version) for m in (g0, g2, c0, c2))
+        hit = getattr(self, "_tcs_stems_bd", None)
+        if hit is None or hit[0] != key:
+            dev = g0.weight.device
+            ng, nc = g0.out_channels, c0.out_channels                       # 32, 64
+            w1 = torch.zeros(ng + nc, g0.in_channels + c0.in_channels, 3, 3, device=dev)
+            w1[:ng, :g0.in_channels] = g0.weight.detach()
+            w1[ng:, g0.in_channels:] = c0.weight.detach()
+            w2 = torch.zeros(g2.out_channels + c2.out_channels, ng + nc, 3, 3, device=dev)
+            w2[:g2.out_channels, :ng] = g2.weight.detach()
+            w2[g2.out_channels:, ng:] = c2.weight.detach()
+            b1 = torch.cat([g0.bias.detach(), c0.bias.detach()])
+            b2 = torch.cat([g2.bias.detach(), c2.bias.detach()])
+            hit = (key, (ops.pack_conv(w1, b1, "f32"), ops.pack_conv(w2, b2, "f16x3")))
+            self._tcs_stems_bd = hit
+        return hit[1]
+
     def prepare(self, pool, clist):
         """Once per frame.  conv_4_4 / conv_8_8 / conv_16_16 read cat(features, clist[i]) (update.py:205-209) and `clist` does
         not change over the iterations, so its share of each convolution (40 % / 40 % / 33 % of the input channels) is
@@ -574,8 +595,21 @@ class DispGradPredictor(nn.Module):
         def stem_c():
             return conv16(pool, self.conv_grad_candidate_stem[2], [conv32to16(pool, self.conv_grad_candidate_stem[0], cands, act="relu")])
 
-        x4_cand, x4_grad = fork_join([stem_c, stem_g], site="stems")       # the longer chain (fp32-MFMA candidate stem) on the origin stream
-        x4 = feat(self.conv_4_4[0], [x4_grad, x4_cand], pre[0])
+        if "nostemsbd" not in _X:
+            # the two stems (update.py:200-205) as ONE chain of two launches: their first layers read different tensors and their second
+            # layers different halves, so cat(grad stem, candidate stem) is a convolution with block-diagonal weights — 34 -> 96 on the
+            # fp32-MFMA kernel (the candidates are unbounded), then 96 -> 96 on S16.  The zero blocks add exact zeros; the extra MACs
+            # are nothing (these layers cost their launch, not their arithmetic), and a fork / join across queues (~10 us each way
+            # on this stack) and two launches leave the iteration's serial chain.
+            pc1, pc2 = self._stems_block_diagonal()
+            a1 = pool.get((id(self), "stems1"), g5.shape[0], 96, g5.shape[2], g5.shape[3], g5.device)
+            ops.conv2d(pc1, [g5, cands], act="relu", out16=a1)
+            x4_stems = pool.get((id(self), "stems2"), g5.shape[0], 96, g5.shape[2], g5.shape[3], g5.device)
+            s16.conv2d(pc2, [a1], out16=x4_stems)
+            x4 = feat(self.conv_4_4[0], [x4_stems], pre[0])
+        else:
+            x4_cand, x4_grad = fork_join([stem_c, stem_g], site="stems")   # the longer chain (fp32-MFMA candidate stem) on the origin stream
+            x4 = feat(self.conv_4_4[0], [x4_grad, x4_cand], pre[0])
         x8 = conv16(pool, self.conv_4_8[0], [x4], act="relu")                    # 3x3 stride 2
         x8 = feat(self.conv_8_8[0], [x8], pre[1])
         x16 = conv16(pool, self.conv_8_16[0], [x8], act="relu")                  # 3x3 stride 2
@@ -650,7 +684,10 @@ class DispRefine(nn.Module):
             c = conv16(pool, self.context_compress[0], [context_disp, context_grad], act="relu")
             return conv16(pool, self.context_compress[2], [c])
 
-        context, (cand9, disp_f) = fork_join([ctx_branch, cand_branch], site="refine")
+        if "swaprefine" in _X:
+            (cand9, disp_f), context = fork_join([cand_branch, ctx_branch], site="refine")
+        else:
+            context, (cand9, disp_f) = fork_join([ctx_branch, cand_branch], site="refine")
         fused = conv16(pool, self.conv_fuse[0], [disp_f, context], act="relu")
         fused = conv16(pool, self.conv_fuse[2], [fused], act="relu")
         w = conv16(pool, self.w_head[0], [fused], act="relu")

@@ -33,6 +33,9 @@ SHAPES = [  # name, (cins...), cout, k, H, W, epilogue, stride
     ("head 256->1", (256,), 1, 3, 120, 160, "lin", 1),
     ("head 128->2", (128,), 2, 3, 120, 160, "lin", 1),
     ("s2 64->96", (64,), 96, 3, 120, 160, "lin", 2),
+    ("full 64->64", (64,), 64, 3, 480, 640, "lin", 1),          # feature extractor, layer1 at full resolution (run with BATCH=2)
+    ("half 96->96", (96,), 96, 3, 240, 320, "lin", 1),          # layer2
+    ("quarter 128->128", (128,), 128, 3, 120, 160, "lin", 1),   # layer3 / heads
     ("deconv 128->96", (128,), 96, 3, 30, 40, "deconv", 1),
 ]
 CFGS3 = [101412, 101812, 101411, 102411, 101811, 102812, 102512]
