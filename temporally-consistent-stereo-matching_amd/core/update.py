@@ -112,8 +112,9 @@ def tap_partials(pool, conv1: nn.Conv2d, conv2: nn.Conv2d, srcs, pc=None, out16b
     ntile = (conv1.out_channels + 31) // 32
     taps = s16.Taps(pool.get32((id(conv2), "taps"), (a.B, ntile, 9 * conv2.out_channels, a.H, a.W), a.device), ntile, conv2.out_channels,
                     None if conv2.bias is None else conv2.bias.detach())
+    tc = 121812 if ("rpwfh" in _X and a.H * a.W >= 10000 and conv1.kernel_size[0] == 3) else 0
     s16.conv2d(packed16(conv1) if pc is None else pc, srcs, act="relu", taps=taps, tap_weights=tap_weights(conv2), out16b=out16b,
-               out16_split=conv1.out_channels if out16b is not None else 0)
+               out16_split=conv1.out_channels if out16b is not None else 0, tile_cfg=tc)
     return taps
 
 
@@ -271,8 +272,10 @@ class _GateCell(nn.Module):
         """The same cell on S16 tensors, updating `h` IN PLACE (two launches; z stays fp32, r*h is an S16 temporary)."""
         z = pool.get32((id(self), "z"), (h.B, h.C, h.H, h.W), h.device)
         rh = pool.get((id(self), "rh"), h.B, h.C, h.H, h.W, h.device)
-        s16.gru_gates(packed16(self.convzr), [h, *xs], h, cz, cr, z_out=z, rh_out=rh)
-        return s16.gru_update(packed16(self.convq), [rh, *xs], h, z, cq, keep_z=self.keep_z, out=h)
+        big = h.H * h.W >= 10000 and self.convzr.kernel_size[0] == 3
+        s16.gru_gates(packed16(self.convzr), [h, *xs], h, cz, cr, z_out=z, rh_out=rh, tile_cfg=121812 if (big and "rpwzr" in _X) else 0)
+        return s16.gru_update(packed16(self.convq), [rh, *xs], h, z, cq, keep_z=self.keep_z, out=h,
+                              tile_cfg=121812 if (big and "rpwq" in _X) else 0)
 
 
 class ConvGRU(_GateCell):
@@ -595,12 +598,12 @@ class DispGradPredictor(nn.Module):
         def stem_c():
             return conv16(pool, self.conv_grad_candidate_stem[2], [conv32to16(pool, self.conv_grad_candidate_stem[0], cands, act="relu")])
 
-        if "nostemsbd" not in _X:
-            # the two stems (update.py:200-205) as ONE chain of two launches: their first layers read different tensors and their second
-            # layers different halves, so cat(grad stem, candidate stem) is a convolution with block-diagonal weights — 34 -> 96 on the
-            # fp32-MFMA kernel (the candidates are unbounded), then 96 -> 96 on S16.  The zero blocks add exact zeros; the extra MACs
-            # are nothing (these layers cost their launch, not their arithmetic), and a fork / join across queues (~10 us each way
-            # on this stack) and two launches leave the iteration's serial chain.
+        if "stemsbd" in _X:
+            # OFF by default (A/B token "stemsbd"; measured +0.25 ms per frame against the forked stems, twice on one box).  The two stems
+            # (update.py:200-205) as ONE chain of two launches: their first layers read different tensors and their second layers
+            # different halves, so cat(grad stem, candidate stem) is a convolution with block-diagonal weights — 34 -> 96 on the
+            # fp32-MFMA kernel (the candidates are unbounded), then 96 -> 96 on S16.  The zero blocks add exact zeros; two launches and a
+            # fork / join leave the serial chain, but the two launches that remain are slower than the forked pairs they replace.
             pc1, pc2 = self._stems_block_diagonal()
             a1 = pool.get((id(self), "stems1"), g5.shape[0], 96, g5.shape[2], g5.shape[3], g5.device)
             ops.conv2d(pc1, [g5, cands], act="relu", out16=a1)
