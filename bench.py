@@ -61,7 +61,7 @@ class ClipRunner:
     """Steps through device-resident clips, carrying the temporal state like evaluate_stereo.py:170-197.  Several
     independent sequences can ride the batch dimension (--seqs-per-gpu); one step = one frame of each."""
 
-    def __init__(self, model, seqs, dev, iters):
+    def __init__(self, model, seqs, dev, iters, prefetch=True):
         from tcs_mi355.harness import InputPadder
         seqs = list(seqs) if isinstance(seqs, (list, tuple)) else [seqs]
         self.model, self.iters, self.n = model, iters, len(seqs[0].frames)
@@ -78,9 +78,15 @@ class ClipRunner:
         self.t = 0
         self.state = None
         self.last = None
+        self.prefetch = prefetch
 
     def step(self):
         i1, i2, K, T = self.frames[self.t]
+        if self.prefetch:
+            # a video loop knows its next frame: its image-only stage (features, correlation pyramid, context) starts now, beside
+            # this frame's refinement loop (TCStereo.prefetch); the clip wraps, and a wrapped frame starts a new sequence
+            nxt = (self.t + 1) % self.n
+            self.model.prefetch(self.frames[nxt][0], self.frames[nxt][1], first=(nxt == 0))
         params = None
         if self.t > 0 and self.state is not None:
             flow_q, nets, fmap1, prev_T = self.state
@@ -358,6 +364,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch kernels eagerly instead of replaying HIP graphs")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="do not start the next frame's image-only stage (feature extraction, correlation pyramid) beside the current frame's loop")
     ap.add_argument("--seqs-per-gpu", type=int, default=1,
                     help="independent sequences stacked on the batch dimension of every launch (default 1 = BASELINE configs[1])")
     ap.add_argument("--size", default=None, metavar="HxW",
@@ -402,7 +410,7 @@ def main():
     S = max(1, a.seqs_per_gpu)
     seqs = [synth.make_sequence(2000 + rank * S + j, n_frames=CLIP_LEN, height=HEIGHT, width=WIDTH, max_disp=MAX_DISP) for j in range(S)]
     seq = seqs[0]
-    runner = ClipRunner(model, seqs, dev, ITERS)
+    runner = ClipRunner(model, seqs, dev, ITERS, prefetch=not a.no_prefetch)
 
     from tcs_mi355 import ops, s16
     with torch.no_grad():
@@ -445,7 +453,7 @@ def main():
             probe = ops.LookupProbe(dev, slots=64)
             ops.LOOKUP_PROBE = probe
             model._graphs = None
-            runner_r = ClipRunner(model, seqs, dev, ITERS)
+            runner_r = ClipRunner(model, seqs, dev, ITERS, prefetch=not a.no_prefetch)
             snaps = []
             for _ in range(2):
                 runner_r.step()
@@ -506,7 +514,7 @@ def main():
           log(f"batched leg: {Sb} sequences per launch")
           seqs_b = [seq] + [synth.make_sequence(2000 + j, n_frames=CLIP_LEN, height=HEIGHT, width=WIDTH, max_disp=MAX_DISP)
                             for j in range(1, Sb)]
-          runner_b = ClipRunner(model, seqs_b, dev, ITERS)
+          runner_b = ClipRunner(model, seqs_b, dev, ITERS, prefetch=not a.no_prefetch)
           with torch.no_grad():
               for _ in range(2):
                   runner_b.step()
@@ -520,7 +528,7 @@ def main():
               # stamped pass for the lookup's in-frame duration at this batch size
               ops.LOOKUP_PROBE = probe_b = ops.LookupProbe(dev, slots=64)
               model._graphs = None
-              runner_s = ClipRunner(model, seqs_b, dev, ITERS)
+              runner_s = ClipRunner(model, seqs_b, dev, ITERS, prefetch=not a.no_prefetch)
               snaps_b = []
               for _ in range(2):
                   runner_s.step()
@@ -559,7 +567,9 @@ def main():
                                    + " synthetic sequence len=10, D=192, 32 iters, "
                                    + ("one sequence per GPU" if S == 1 else f"{S} independent sequences batched per GPU"),
                        "frames_per_rank": a.steps * S, "seqs_per_gpu": S, "weights": "key-seeded synthetic (tcs_mi355.weights)",
-                       "launch": "eager" if a.eager else "hip-graph replay"},
+                       "launch": ("eager" if a.eager else "hip-graph replay") + ("" if a.no_prefetch else
+                                  "; the next frame's image-only stage (features, correlation pyramid) starts beside the current frame's loop "
+                                  "(TCStereo.prefetch)")},
             "domain_flags": all_flags,
             "gathered_eval_vs_synthetic_gt": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in gathered_eval.items()},
             "roofline": roof, "cpu_baseline": cpu, "epe_vs_oracle_first_frames": epe_vs_oracle, "batched_leg": batched,

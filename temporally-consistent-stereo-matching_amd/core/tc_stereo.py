@@ -87,7 +87,7 @@ class TCStereo(nn.Module):
         return hash(tuple((p.data_ptr(), p._version) for p in self.parameters()))
 
     # -----------------------------------------------------------------------------------------
-    def _extract(self, image1, image2):
+    def _features(self, image1, image2):
         a = self.args
         if a.shared_backbone:
             *cnet_list, trunk = self.cnet(torch.cat((image1, image2), 0), dual_inp=True, num_layers=a.n_gru_layers)
@@ -98,6 +98,30 @@ class TCStereo(nn.Module):
             fmap1, fmap2 = self.fnet([image1, image2])
         return list(cnet_list), fmap1.float().contiguous(), fmap2.float().contiguous()
 
+    def _pipeline(self):
+        if getattr(self, "_graphs", None) is None:
+            from tcs_mi355.graph import FrameGraphs
+            self._graphs = FrameGraphs(self._extract_stage, self._refine_stage, epoch_fn=self._weights_epoch,
+                                       strict=os.environ.get("TCS_MI355_GRAPH_STRICT", "0") == "1")
+        return self._graphs
+
+    def _graph_mode(self):
+        if getattr(self, "use_hip_graph", None) is None:
+            self.use_hip_graph = os.environ.get("TCS_MI355_GRAPH", "1") != "0"
+        return bool(self.use_hip_graph)
+
+    @torch.no_grad()
+    def prefetch(self, image1, image2, first=False):
+        """Optional, for callers that know the next frame (a video loop): start the part of a frame that depends on nothing but its
+        two images — feature / context networks, correlation pyramid, context convolutions (tc_stereo.py:101-116,147-149) — NOW, on a
+        second stream, beside the refinement loop of the frame in flight.  The next `forward` with the SAME image tensors (same
+        storage, unmodified) picks the result up; any other call simply extracts again.  `first`: that frame will be called with
+        params=None (start of a sequence: the arg-max prior is then built with the correlation volume).  Call it before the
+        `forward` it is to overlap with.  Results are identical with and without it."""
+        if not image1.is_cuda:
+            raise RuntimeError("TCStereo.prefetch needs HIP device tensors; there is no CPU fallback")
+        self._pipeline().prefetch(image1, image2, first=bool(first), use_graph=self._graph_mode())
+
     @torch.no_grad()
     def forward(self, image1, image2, iters=12, params=None, test_mode=False, frame_id=0):
         """Disparity of a stereo pair, optionally conditioned on the previous frame (`params`):
@@ -105,9 +129,9 @@ class TCStereo(nn.Module):
         last_net_list, fmap1.  Returns {'flow' [b,1,H,W] (negative disparity, clipped at 0),
         'flow_q' [b,1,H/4,W/4], 'net_list', 'fmap1'} (tc_stereo.py:96-244).
 
-        The whole frame is a fixed launch sequence with no host round trip, so by default it is
-        captured once per (shape, iters, branch) into a HIP graph and replayed (tcs_mi355.graph);
-        set TCS_MI355_GRAPH=0 or `model.use_hip_graph = False` for eager launches."""
+        A frame is two fixed launch sequences with no host round trip — the image-only stage (`_extract_stage`) and the
+        state-dependent stage (`_refine_stage`) — so by default each is captured once per (shape, iters, branch) into a HIP
+        graph and replayed (tcs_mi355.graph); set TCS_MI355_GRAPH=0 or `model.use_hip_graph = False` for eager launches."""
         if not test_mode:
             raise NotImplementedError("TCStereo on MI355X is inference-only: call with test_mode=True")
         if iters < 1:
@@ -118,40 +142,22 @@ class TCStereo(nn.Module):
         if params is not None:
             temporal = (params["K"], params["T"], params["previous_T"], params["baseline"], params["last_disp"],
                         list(params["last_net_list"]), params["fmap1"])
-        if getattr(self, "use_hip_graph", None) is None:
-            self.use_hip_graph = os.environ.get("TCS_MI355_GRAPH", "1") != "0"
-        if self.use_hip_graph:
-            if getattr(self, "_graphs", None) is None:
-                from tcs_mi355.graph import FrameGraphs
-                self._graphs = FrameGraphs(self._frame, epoch_fn=self._weights_epoch,
-                                           strict=os.environ.get("TCS_MI355_GRAPH_STRICT", "0") == "1")
-            return self._graphs(image1, image2, iters, temporal)
-        return self._frame(image1, image2, iters, temporal)
+        return self._pipeline()(image1, image2, iters, temporal, use_graph=self._graph_mode())
 
     def _frame(self, image1, image2, iters, temporal):
-        """One frame as a pure launch sequence (tensors in, tensors out; capturable)."""
+        """One frame as a pure launch sequence on the current stream (both stages back to back)."""
+        return self._refine_stage(self._extract_stage(image1, image2, temporal is None), iters, temporal)
+
+    def _extract_stage(self, image1, image2, first):
+        """Everything of a frame that depends only on its two images (tensors in, tensors out; capturable): matching features,
+        correlation pyramid (+ the arg-max prior on a first frame), per-scale context terms (tc_stereo.py:101-116,147-149)."""
         a = self.args
         image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
         image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
-        first = temporal is None
-        if not first:
-            K, T, previous_T, baseline, last_disp, last_net_list, last_fmap1 = temporal
-        else:
-            last_net_list = None
 
-        def matching(fmap1, fmap2):
-            """Correlation pyramid + the sparse disparity prior: arg-max of the cost volume (first frame) or the pose warp of
-            the previous frame's disparity and features (tc_stereo.py:121-149)."""
+        def correlate(fmap1, fmap2):
             corr_fn = CorrBlock1D(fmap1, fmap2, radius=a.corr_radius, num_levels=a.corr_levels, thres=a.init_thres, want_argmax=first)
-            if first:
-                return (corr_fn, *corr_fn.argmax_disp(), None)
-            # K_scale, its inverse, T @ inv(previous_T), previous_T @ inv(T): one tiny kernel, no host sync
-            K_scale, K_scale_inv, relative_T, back_T = ops.pose_prepare(K, T, previous_T, self.scale_rate)
-            # warp + normalise + cosine cost in one launch sequence; the warped feature map is never materialised
-            sparse_disp, _, sparse_mask, cost = ops.warp_forward(
-                (-last_disp).float().contiguous(), last_fmap1.float().contiguous(), relative_T, K_scale,
-                K_scale_inv, baseline, cur_fmap=fmap1, want_fmap=False)
-            return corr_fn, sparse_disp, cost, sparse_mask, (K_scale, K_scale_inv, back_T)
+            return corr_fn, (corr_fn.argmax_disp() if first else None)
 
         def context(cnet_list):
             """Per-scale context terms of the GRUs and of the gradient predictor (tc_stereo.py:151-156): once per frame."""
@@ -162,25 +168,42 @@ class TCStereo(nn.Module):
 
         both = torch.cat((image1, image2), 0)
         if a.shared_backbone and self.cnet.can16(both):
-            # the matching side (feature head -> correlation build -> prior) and the context side (per-scale heads -> context
-            # convolutions) both start from the shared trunk and meet at the disparity completion: parallel graph branches
+            # the matching side (feature head -> correlation build) and the context side (per-scale heads -> context convolutions)
+            # both start from the shared trunk: parallel graph branches
             from tcs_mi355.streams import fork_join
             trunk = self.cnet.trunk16(both)
 
             def matching_side():
                 fm = hip_head(self.conv2, trunk)
                 f1, f2 = (t.float().contiguous() for t in fm.split(fm.shape[0] // 2, 0))
-                return f1, f2, matching(f1, f2)
+                return f1, f2, correlate(f1, f2)
 
-            (fmap1, fmap2, match), (inp_list, grad_list, net_list) = fork_join(
+            (fmap1, fmap2, (corr_fn, prior)), (inp_list, grad_list, net_list) = fork_join(
                 [matching_side, lambda: context(self.cnet.heads16(trunk, True, a.n_gru_layers))], site="frame")
         else:
-            cnet_list, fmap1, fmap2 = self._extract(image1, image2)
-            match = matching(fmap1, fmap2)
+            cnet_list, fmap1, fmap2 = self._features(image1, image2)
+            corr_fn, prior = correlate(fmap1, fmap2)
             inp_list, grad_list, net_list = context(cnet_list)
-        corr_fn, sparse_disp, cost, sparse_mask, pose = match
-        if pose is not None:
-            K_scale, K_scale_inv, back_T = pose
+        return {"fmap1": fmap1, "corr_fn": corr_fn, "prior": prior, "inp_list": inp_list, "grad_list": grad_list, "net_list": net_list}
+
+    def _refine_stage(self, feats, iters, temporal):
+        """The state-dependent rest of a frame (tensors in, tensors out; capturable): prior from the arg-max or from the pose warp of
+        the previous frame, disparity completion, hidden-state warp, the refinement loop, upsampling (tc_stereo.py:119-229)."""
+        a = self.args
+        first = temporal is None
+        fmap1, corr_fn = feats["fmap1"], feats["corr_fn"]
+        inp_list, grad_list, net_list = feats["inp_list"], feats["grad_list"], feats["net_list"]
+        if first:
+            last_net_list = None
+            sparse_disp, cost, sparse_mask = feats["prior"] if feats["prior"] is not None else corr_fn.argmax_disp()
+        else:
+            K, T, previous_T, baseline, last_disp, last_net_list, last_fmap1 = temporal
+            # K_scale, its inverse, T @ inv(previous_T), previous_T @ inv(T): one tiny kernel, no host sync
+            K_scale, K_scale_inv, relative_T, back_T = ops.pose_prepare(K, T, previous_T, self.scale_rate)
+            # warp + normalise + cosine cost in one launch sequence; the warped feature map is never materialised
+            sparse_disp, _, sparse_mask, cost = ops.warp_forward(
+                (-last_disp).float().contiguous(), last_fmap1.float().contiguous(), relative_T, K_scale,
+                K_scale_inv, baseline, cur_fmap=fmap1, want_fmap=False)
 
         disp_init, _, _, net_list = self.disp_completor(sparse_disp, cost, sparse_mask, net_list)
         disp_init = disp_init.float().contiguous()

@@ -1,22 +1,24 @@
-"""HIP-graph replay of a whole TC-Stereo frame.
+"""A TC-Stereo frame as a two-stage pipeline, replayed from HIP graphs.
 
-One frame is ~1,800 kernel launches with static shapes and no host decision inside, so the launch
-sequence is captured once per (input shape, iteration count, first-frame / temporal branch) and
-replayed.  Inputs are copied into the graph's static buffers, outputs are cloned out, so callers
-keep ordinary tensor semantics (the temporal state they pass back next frame is theirs).  The
-library kernels are capture-safe by construction (no allocation, no sync, stream-ordered memset
-only — include/tcs_mi355.h); the PyTorch-ROCm parts (extractor, U-Nets) are captured by torch.
+A frame has two parts.  EXTRACT — image normalisation, feature / context networks, correlation pyramid, context convolutions
+(core/tc_stereo.py:101-116,147-149 of the reference) — depends on nothing but the two images.  REFINE — the temporal warp or
+arg-max prior, disparity completion, hidden-state warp and the refinement loop (tc_stereo.py:119-229) — needs EXTRACT's
+features and the previous frame's outputs.  Frames of a sequence are serial through REFINE only, so the EXTRACT of frame t+1
+can run while the REFINE of frame t still does: `prefetch(image1, image2)` launches it on a second stream into the free one
+of two feature slots, and the following `__call__` with the same image tensors finds it there.  The refinement loop leaves
+about half of the GPU idle at one 640x480 sequence (150-600 workgroup launches on 256 CUs), which is where the ~2 ms of
+feature extraction go.  Without a prefetch the two stages simply run back to back, as the reference does.
 
-Two instantiations per key, used in turn (`copies`, TCS_MI355_GRAPH_COPIES).  On ROCm 7.2 a graph WITH parallel branches
-(tcs_mi355/streams.py) is not fire-and-forget: launching an executable graph again blocks the host until its previous
-launch has nearly finished (median 19 ms per 28 ms frame; a linear graph returns in 0.7 ms), so the host can never run
-ahead and every scheduling hiccup becomes a GPU bubble.  Alternating between two executables of the same capture lets
-the host enqueue frame t+1 while frame t runs (6.5 ms per launch, tools/capture_variance.py).  Both use the same static
-input buffers and the same persistent pool buffers; stream order keeps their replays sequential on the GPU.
+Each stage is ~100 / ~1,700 kernel launches with static shapes and no host decision inside, so it is captured once per
+(shape, branch[, iteration count]) and slot into a HIP graph and replayed.  Inputs are copied into the graph's static
+buffers, outputs are cloned out, so callers keep ordinary tensor semantics (the temporal state they pass back next frame
+is theirs).  The library kernels are capture-safe by construction (no allocation, no sync — include/tcs_mi355.h).
+Two slots also give two executables per stage, used in turn: on ROCm 7.2 launching an executable graph WITH parallel
+branches again blocks the host until its previous launch has nearly finished (tools/capture_variance.py), and alternating
+lets the host enqueue frame t+1 while frame t runs.
 """
 from __future__ import annotations
 
-import os
 import warnings
 from typing import Callable, Dict, List, Optional
 
@@ -36,79 +38,237 @@ def _unflatten(flat):
     return (flat[0], flat[1], flat[2], flat[3], flat[4], list(flat[5:-1]), flat[-1])
 
 
+def _tensors(obj, seen=None):
+    """Every torch tensor reachable from a feature bundle (lists, tuples, dicts, objects with __dict__)."""
+    seen = set() if seen is None else seen
+    if id(obj) in seen:
+        return
+    seen.add(id(obj))
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            yield from _tensors(o, seen)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            yield from _tensors(o, seen)
+    elif hasattr(obj, "__dict__"):
+        for o in vars(obj).values():
+            yield from _tensors(o, seen)
+
+
+class _Slot:
+    """One of the two feature slots: what the last EXTRACT into it produced, and the events that order its reuse."""
+
+    def __init__(self):
+        self.feats = None
+        self.token = None                      # identifies the images (and mode) the features belong to
+        self.ex_key = None
+        self.ready = torch.cuda.Event()        # EXTRACT done (recorded on the extract stream)
+        self.free = torch.cuda.Event()         # the REFINE that read the features is done (recorded on the caller's stream)
+
+
 class _Entry:
     def __init__(self, graph, static_in, static_out):
         self.graph, self.static_in, self.static_out = graph, static_in, static_out
 
 
 class FrameGraphs:
-    """`epoch_fn` returns a value that changes whenever a model parameter is replaced or written in place
-    (`load_state_dict`, an optimiser step): a captured graph holds the packed weight images of the moment of capture,
-    so every entry is dropped and re-captured when it changes.  `fell_back` counts the frames that ran eagerly because
-    a capture failed; `strict=True` turns such a failure into an error instead (bench.py, tests)."""
+    """`extract_fn(image1, image2, first) -> feats`, `refine_fn(feats, iters, temporal) -> dict`.
 
-    def __init__(self, frame_fn: Callable, warmup: int = 2, epoch_fn: Optional[Callable[[], object]] = None, strict: bool = False,
-                 copies: Optional[int] = None):
-        self.frame_fn, self.warmup, self.epoch_fn, self.strict = frame_fn, warmup, epoch_fn, strict
-        self.copies = max(1, int(os.environ.get("TCS_MI355_GRAPH_COPIES", "2")) if copies is None else int(copies))
-        self.turn: Dict[tuple, int] = {}
-        self.cache: Dict[tuple, Optional[List[_Entry]]] = {}
+    `epoch_fn` returns a value that changes whenever a model parameter is replaced or written in place (`load_state_dict`, an
+    optimiser step): a captured graph holds the packed weight images of the moment of capture, so every entry is dropped and
+    re-captured when it changes.  `fell_back` counts the frames that ran eagerly because a capture failed; `strict=True` turns
+    such a failure into an error instead (bench.py, tests).  `captures` counts captured REFINE keys."""
+
+    def __init__(self, extract_fn: Callable, refine_fn: Callable, warmup: int = 2, epoch_fn: Optional[Callable[[], object]] = None,
+                 strict: bool = False):
+        self.extract_fn, self.refine_fn, self.warmup, self.epoch_fn, self.strict = extract_fn, refine_fn, warmup, epoch_fn, strict
+        self.slots = [_Slot(), _Slot()]
+        self.turn = 0                          # the slot the next EXTRACT goes to
+        self.pending: Optional[int] = None     # slot of a prefetch nobody has consumed yet
+        self.ex: Dict[tuple, Optional[List[_Entry]]] = {}
+        self.rf: Dict[tuple, Optional[List[_Entry]]] = {}
         self.epoch = epoch_fn() if epoch_fn is not None else None
         self.fell_back = 0
         self.captures = 0
+        self.prefetched = 0                    # frames whose EXTRACT had been launched by prefetch()
+        self._sx: Dict[object, torch.cuda.Stream] = {}
 
-    def _key(self, image1, iters, flat):
+    # ---- bookkeeping ---------------------------------------------------------------------------------------------------------
+    @property
+    def cache(self):
+        return {**{("extract", *k): v for k, v in self.ex.items()}, **{("refine", *k): v for k, v in self.rf.items()}}
+
+    def _check_epoch(self):
+        if self.epoch_fn is not None:
+            now = self.epoch_fn()
+            if now != self.epoch:              # weights changed: the captured packed-weight images are stale
+                torch.cuda.synchronize()
+                self.ex.clear()
+                self.rf.clear()
+                self.slots = [_Slot(), _Slot()]
+                self.pending, self.turn, self.epoch = None, 0, now
+
+    def _stream(self, device) -> torch.cuda.Stream:
+        st = self._sx.get(device)
+        if st is None:
+            st = self._sx[device] = torch.cuda.Stream(device=device)
+        return st
+
+    @staticmethod
+    def _token(image1, image2, first, use_graph):
+        return (image1.data_ptr(), image1._version, image2.data_ptr(), image2._version, tuple(image1.shape), bool(first), bool(use_graph))
+
+    @staticmethod
+    def _ex_key(image1, first):
+        return (tuple(image1.shape), image1.device.index, bool(first))
+
+    @staticmethod
+    def _rf_key(image1, iters, flat):
         return (tuple(image1.shape), image1.device.index, int(iters), tuple(tuple(t.shape) for t in flat))
 
-    def _capture(self, image1, image2, iters, flat) -> Optional[_Entry]:
-        static_in = [image1.clone(), image2.clone()] + [t.detach().float().clone() for t in flat]
-        run = lambda: self.frame_fn(static_in[0], static_in[1], iters, _unflatten(static_in[2:]))
+    # ---- EXTRACT -------------------------------------------------------------------------------------------------------------
+    def _capture_extract(self, key, image1, image2, first) -> Optional[List[_Entry]]:
+        static_in = [image1.clone(), image2.clone()]
+        run = lambda: self.extract_fn(static_in[0], static_in[1], first)
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                for _ in range(self.warmup):        # packs weights, lets MIOpen pick algorithms, sizes the pools
+                for _ in range(self.warmup):        # packs weights, sizes the pools
                     run()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             entries = []
-            for _ in range(self.copies):
+            for _ in range(2):                      # one executable (and one set of output tensors) per slot
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    feats = run()
+                g.replay()          # the first launch of an executable graph uploads it (~30 ms): pay that here, not in a timed frame
+                entries.append(_Entry(g, static_in, feats))
+            torch.cuda.synchronize()
+            return entries
+        except Exception as e:  # capture is an optimisation: the eager HIP path computes the same thing
+            if self.strict:
+                raise
+            warnings.warn(f"HIP graph capture of the extract stage failed ({type(e).__name__}: {e}); running this shape with eager launches")
+            torch.cuda.synchronize()
+            return None
+
+    def _launch_extract(self, si: int, image1, image2, first: bool, use_graph: bool):
+        """EXTRACT into slot `si` on the extract stream: after everything queued on the caller's stream so far (the images are
+        ready; every earlier REFINE is ahead of us in that order, in particular the one that read this slot) and after the slot's
+        last reader."""
+        slot = self.slots[si]
+        main = torch.cuda.current_stream()
+        sx = self._stream(image1.device)
+        key = self._ex_key(image1, first)
+        entries = None
+        if use_graph:
+            if key not in self.ex:
+                self.ex[key] = self._capture_extract(key, image1, image2, first)
+            entries = self.ex[key]
+        here = torch.cuda.Event()
+        here.record(main)
+        sx.wait_event(here)
+        sx.wait_event(slot.free)
+        with torch.cuda.stream(sx):
+            if entries is not None:
+                e = entries[si]
+                e.static_in[0].copy_(image1)
+                e.static_in[1].copy_(image2)
+                e.graph.replay()
+                slot.feats = e.static_out
+            else:
+                slot.feats = self.extract_fn(image1, image2, first)
+                for t in _tensors(slot.feats):       # allocated on the extract stream, read on the caller's: keep the blocks alive for it
+                    t.record_stream(main)
+            slot.ready.record(sx)
+        slot.token, slot.ex_key = self._token(image1, image2, first, use_graph), key
+
+    def prefetch(self, image1, image2, first: bool = False, use_graph: bool = True) -> int:
+        """Launch the EXTRACT stage of a coming frame now (beside whatever the GPU is still doing); the next `__call__` with the same
+        image tensors (same storage, unmodified) uses it.  Call it BEFORE the `__call__` it is to overlap with.  Returns the slot."""
+        self._check_epoch()
+        si = self.pending if self.pending is not None else self.turn      # an unused prefetch is simply replaced
+        self._launch_extract(si, image1, image2, first, use_graph)
+        self.pending = si
+        self.turn = si ^ 1
+        return si
+
+    # ---- REFINE --------------------------------------------------------------------------------------------------------------
+    def _capture_refine(self, key, image1, image2, iters, flat, first) -> Optional[List[_Entry]]:
+        ex_key = self._ex_key(image1, first)
+        try:
+            for si in (0, 1):                        # both slots need features of this shape / branch to capture against
+                if self.slots[si].feats is None or self.slots[si].ex_key != ex_key or self.ex.get(ex_key) is None \
+                        or self.slots[si].feats is not self.ex[ex_key][si].static_out:
+                    self._launch_extract(si, image1, image2, first, True)
+            if self.ex.get(ex_key) is None:
+                return None                          # the extract stage runs eagerly: so does this one
+            torch.cuda.synchronize()
+            static_in = [t.detach().float().clone() for t in flat]
+            entries = []
+            for si in (0, 1):
+                feats = self.ex[ex_key][si].static_out
+                run = lambda: self.refine_fn(feats, iters, _unflatten(static_in))
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(self.warmup if si == 0 else 1):
+                        run()
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     out = run()
-                g.replay()          # the first launch of an executable graph uploads it (~30 ms): pay that here, not in a timed frame;
-                                    # a replay only rewrites the graph's own buffers and the pool, so repeating the frame is harmless
+                g.replay()
                 entries.append(_Entry(g, static_in, out))
             torch.cuda.synchronize()
             self.captures += 1
             return entries
-        except Exception as e:  # capture is an optimisation: the eager HIP path computes the same thing
+        except Exception as e:
             if self.strict:
                 raise
             warnings.warn(f"HIP graph capture failed ({type(e).__name__}: {e}); running this shape with eager launches")
             torch.cuda.synchronize()
             return None
 
-    def __call__(self, image1, image2, iters, temporal):
+    def __call__(self, image1, image2, iters, temporal, use_graph: bool = True):
+        self._check_epoch()
         flat = _flatten(temporal)
-        if self.epoch_fn is not None:
-            now = self.epoch_fn()
-            if now != self.epoch:                  # weights changed: the captured packed-weight images are stale
-                self.cache.clear()
-                self.epoch = now
-        key = self._key(image1, iters, flat)
-        if key not in self.cache:
-            self.cache[key] = self._capture(image1, image2, iters, flat)
-        entries = self.cache[key]
-        if entries is None:
-            self.fell_back += 1
-            return self.frame_fn(image1, image2, iters, temporal)
-        turn = self.turn.get(key, 0)
-        self.turn[key] = (turn + 1) % len(entries)
-        e = entries[turn]
-        for dst, src in zip(e.static_in, [image1, image2, *flat]):
-            dst.copy_(src)
-        e.graph.replay()
-        o = e.static_out
-        return {"flow": o["flow"].clone(), "flow_q": o["flow_q"].clone(), "net_list": [t.clone() for t in o["net_list"]],
-                "fmap1": o["fmap1"].clone()}
+        first = temporal is None
+        token = self._token(image1, image2, first, use_graph)
+        entries = None
+        if use_graph:
+            key = self._rf_key(image1, iters, flat)
+            if key not in self.rf:
+                self.rf[key] = self._capture_refine(key, image1, image2, iters, flat, first)
+            entries = self.rf[key]
+            if entries is None:
+                self.fell_back += 1
+        if self.pending is not None and self.slots[self.pending].token == token:
+            si = self.pending
+            self.prefetched += 1
+        else:
+            si = self.pending if self.pending is not None else self.turn
+            self._launch_extract(si, image1, image2, first, use_graph and entries is not None)
+            self.turn = si ^ 1
+        self.pending = None
+        slot = self.slots[si]
+        main = torch.cuda.current_stream()
+        main.wait_event(slot.ready)
+        if entries is not None and self.ex.get(slot.ex_key) is not None and slot.feats is self.ex[slot.ex_key][si].static_out:
+            e = entries[si]
+            for dst, src in zip(e.static_in, flat):
+                dst.copy_(src)
+            e.graph.replay()
+            o = e.static_out
+            out = {"flow": o["flow"].clone(), "flow_q": o["flow_q"].clone(), "net_list": [t.clone() for t in o["net_list"]],
+                   "fmap1": o["fmap1"].clone()}
+        else:
+            out = self.refine_fn(slot.feats, iters, temporal)
+            out = dict(out, fmap1=out["fmap1"].clone())      # the slot's tensor is overwritten two frames from now
+        slot.free.record(main)
+        return out

@@ -331,7 +331,9 @@ def instance_norm(x: S16, act: str = "none", addend: Optional[S16] = None, eps: 
     if (out.B, out.H, out.W, out.G) != (x.B, x.H, x.W, x.G):
         raise ValueError("instance_norm: bad `out`")
     L = nv.lib()
-    key = (x.B, x.G, x.H, x.W, str(x.device))
+    # one workspace per INPUT buffer (pool buffers live as long as the model): two launch sequences that run side by side (the extract
+    # stage of the next frame beside the loop of the current one) never share the partial statistics
+    key = (x.data.data_ptr(), x.B, x.G, x.H, x.W, str(x.device))
     ws = _IN_WS.get(key)
     if ws is None:
         ws = _IN_WS[key] = torch.empty(L.tcs_instance_norm_s16_workspace_bytes(x.B, x.G, x.H, x.W) // 4, dtype=torch.float32, device=x.device)

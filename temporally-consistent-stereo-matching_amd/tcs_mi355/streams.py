@@ -26,11 +26,34 @@ _DEPTH = 0          # nesting level of fork_join: each level owns its own side s
 _IN_SIDE = 0        # > 0 while a side branch is being enqueued
 
 
-def _side_streams(device, depth: int, n: int) -> List[torch.cuda.Stream]:
-    pool = _POOL.setdefault((device, depth), [])
+def _side_streams(device, depth: int, n: int, origin: int = 0) -> List[torch.cuda.Stream]:
+    """Side streams of one origin stream and nesting depth: two launch sequences enqueued on different origin streams (the extract
+    stage of the next frame beside the refinement of the current one, tcs_mi355/graph.py) never share a side stream."""
+    pool = _POOL.setdefault((device, depth, origin), [])
     while len(pool) < n:
         pool.append(torch.cuda.Stream(device=device))
     return pool[:n]
+
+
+def _keep_alive(obj, stream, seen=None):
+    """Eager launches only: tensors a side chain allocated (on its side stream) and hands to the origin stream must not be
+    given to another allocation while the origin stream still reads them — `record_stream` tells the caching allocator.
+    (Under graph capture every allocation is static: nothing to do.)"""
+    seen = set() if seen is None else seen
+    if id(obj) in seen:
+        return
+    seen.add(id(obj))
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            _keep_alive(o, stream, seen)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            _keep_alive(o, stream, seen)
+    elif hasattr(obj, "data") and torch.is_tensor(getattr(obj, "data")):          # s16.S16
+        _keep_alive(obj.data, stream, seen)
 
 
 class Spawned:
@@ -48,7 +71,7 @@ def spawn(fn: Callable[[], object], site: str = "", slot: int = 0) -> Spawned:
     if not ENABLED or _IN_SIDE > 0 or not torch.cuda.is_available() or ("all" not in SITES and site not in SITES):
         return Spawned(fn(), None)
     cur = torch.cuda.current_stream()
-    pool = _POOL.setdefault((cur.device, "spawn"), [])
+    pool = _POOL.setdefault((cur.device, "spawn", cur.cuda_stream), [])
     while len(pool) <= slot:
         pool.append(torch.cuda.Stream(device=cur.device))
     st = pool[slot]
@@ -64,7 +87,10 @@ def spawn(fn: Callable[[], object], site: str = "", slot: int = 0) -> Spawned:
 
 def join(h: Spawned):
     if h is not None and h.stream is not None:
-        torch.cuda.current_stream().wait_stream(h.stream)
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(h.stream)
+        if not torch.cuda.is_current_stream_capturing():
+            _keep_alive(h.result, cur)
     return None if h is None else h.result
 
 
@@ -78,7 +104,7 @@ def fork_join(fns: Sequence[Callable[[], object]], site: str = "") -> list:
     if _IN_SIDE > 0:
         return [f() for f in fns]          # a side branch never forks again (ROCm 7.2 hipStreamEndCapture crash, see above)
     cur = torch.cuda.current_stream()
-    sides = _side_streams(cur.device, _DEPTH, len(fns) - 1)
+    sides = _side_streams(cur.device, _DEPTH, len(fns) - 1, cur.cuda_stream)
     results = [None] * len(fns)
     _DEPTH += 1
     try:
@@ -95,4 +121,7 @@ def fork_join(fns: Sequence[Callable[[], object]], site: str = "") -> list:
         _DEPTH -= 1
     for st in sides:
         cur.wait_stream(st)
+    if not torch.cuda.is_current_stream_capturing():
+        for r in results[1:]:
+            _keep_alive(r, cur)
     return results

@@ -540,6 +540,51 @@ def test_graph_replay_matches_eager(dev, model):
         assert epe(graphed[t], eager[t]) <= 1e-5 and epe(again[t], eager[t]) <= 1e-5, t
 
 
+def test_prefetch_overlaps_the_next_frames_extract_stage_without_changing_results(dev, model):
+    """TCStereo.prefetch: the image-only stage of frame t+1 launched on a second stream beside the refinement of frame t
+    (tcs_mi355/graph.py).  Same kernels on the same data: frame 0 (no splat atomics) must be bit-identical with and without it,
+    temporal frames within the atomics' jitter; a prefetch for other images than the next call's is discarded, not used."""
+    from tcs_mi355 import synth
+    from tcs_mi355.harness import InputPadder
+    seq = synth.make_sequence(13, n_frames=4, height=96, width=160, max_disp=32.0)
+    K_raw = torch.as_tensor(seq.K, dtype=torch.float32, device=dev)[None]
+    baseline = torch.tensor([seq.baseline], dtype=torch.float32, device=dev)
+    frames = []
+    for fr in seq.frames:
+        im1, im2 = D(fr.image1, dev)[None], D(fr.image2, dev)[None]
+        padder = InputPadder(im1.shape, divis_by=32)
+        (im1, im2), K = padder.pad(im1, im2, K=K_raw)
+        frames.append((im1.contiguous(), im2.contiguous(), K, D(fr.T, dev)[None]))
+
+    def run(prefetch, wrong_first=False):
+        outs, state = [], None
+        for t, (i1, i2, K, T) in enumerate(frames):
+            if prefetch and t + 1 < len(frames):
+                nxt = frames[t + 1] if not (wrong_first and t == 0) else frames[-1]         # a prefetch that will not be used
+                model.prefetch(nxt[0], nxt[1], first=False)
+            params = None if state is None else dict(K=K, T=T, previous_T=state[3], last_disp=state[0], last_net_list=state[1], fmap1=state[2],
+                                                     baseline=baseline)
+            o = model(i1, i2, iters=3, test_mode=True, params=params)
+            state = (o["flow_q"], o["net_list"], o["fmap1"], T)
+            outs.append(o["flow"].clone())
+        return outs
+
+    saved = getattr(model, "use_hip_graph", None)
+    try:
+        for graph in (True, False):
+            model.use_hip_graph = graph
+            plain = run(False)
+            n0 = model._graphs.prefetched
+            piped = run(True)
+            assert model._graphs.prefetched - n0 == len(frames) - 1         # every frame but the first found its features waiting
+            odd = run(True, wrong_first=True)
+            assert torch.equal(piped[0], plain[0]) and torch.equal(odd[0], plain[0])
+            for t in range(1, len(frames)):
+                assert epe(piped[t], plain[t]) <= 1e-5 and epe(odd[t], plain[t]) <= 1e-5, (graph, t)
+    finally:
+        model.use_hip_graph = saved
+
+
 def test_graph_recaptures_when_weights_change(dev, synth_weights):
     """A captured frame graph holds the packed weight images of its capture: after load_state_dict (or any in-place
     parameter write) the cache must be dropped, or replays would mix old packed weights with new biases."""
