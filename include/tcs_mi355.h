@@ -15,7 +15,8 @@
  *    Nothing is allocated, freed or synchronised inside; all work is enqueued on `stream`
  *    (a hipStream_t passed as void*; NULL = the default stream).  Safe under HIP graph capture.
  *  - Return value: 0 on success, negative TCS_E* otherwise.  Never throws, never exits.
- *  - Re-entrant per stream; no global mutable state.
+ *  - Re-entrant per stream.  The only mutable global state is the set of device-side S16 domain-flag words, written by kernels on
+ *    a domain violation and read-and-cleared by tcs_s16_flags / tcs_s16_flags_detail (which synchronise the device).
  */
 #ifndef TCS_MI355_H
 #define TCS_MI355_H
@@ -190,7 +191,8 @@ int tcs_avgpool3s2(const float* x, int B, int C, int H, int W, float* out, tcs_s
 int tcs_resize_bilinear(const float* x, int B, int C, int H, int W, int Ho, int Wo, float* out, tcs_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Convolutions of the update step on the matrix cores (fp32-in / fp32-accumulate MFMA)
+ * Convolutions on the matrix cores, fp32 NCHW tensors in and out: fp32 MFMA (TCS_MATH_F32) or fp16-split operands with fp32
+ * accumulation (TCS_MATH_F16X3, the default of the Python mirror) — see tcs_conv_desc.math
  * ---------------------------------------------------------------------------------------------- */
 #define TCS_ACT_NONE 0
 #define TCS_ACT_RELU 1
@@ -240,6 +242,13 @@ typedef struct tcs_conv_desc {
                                 fp32 tensor (correlation features, disparity stencils) hands its result to tcs_conv2d_s16 consumers
                                 without a conversion pass; `out` may then be NULL */
     int out16_groups, out16_group_offset;
+    /* 7x7 RGB stem only (Cin = 3): the image preparation of TCStereo.forward folded into its input staging (core/tc_stereo.py:101-107).
+     * in_transform = 1: every in-image sample x is read as 2 * (x / 255) - 1 (padding stays 0).  src_batch2 / batch_split: batch
+     * elements >= batch_split come from this second tensor [B - batch_split, 3, H, W] instead of src[0] — torch.cat((image1, image2), 0)
+     * without the copy.  0 / NULL = off. */
+    int in_transform;
+    const float* src_batch2;
+    int batch_split;
 } tcs_conv_desc;
 
 /* packed weight size in floats for a [Cout,Cin,k,k] convolution */

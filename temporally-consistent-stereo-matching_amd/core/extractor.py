@@ -118,16 +118,17 @@ def _s16_ok(kind: str, hw: int) -> bool:
     return kind == "none" or (kind == "instance" and hw <= 40960)
 
 
-def hip_head16(pool, f, x: "s16.S16") -> torch.Tensor:
-    """An output head on an S16 trunk tensor -> fp32 NCHW (what the correlation build / context convolutions consume)."""
+def hip_head16(pool, f, x: "s16.S16", act: str = "none") -> torch.Tensor:
+    """An output head on an S16 trunk tensor -> fp32 NCHW (what the correlation build / context convolutions consume); `act`: an
+    activation the caller would apply next, in the final convolution's epilogue."""
     from core.update import conv16
     if isinstance(f, nn.Sequential):
         for m in f:
             if isinstance(m, nn.Conv2d):
-                return conv16(pool, m, [x], want32=True)
+                return conv16(pool, m, [x], act=act, want32=True)
             x = m.run16(pool, x)
         raise ValueError("head without a final convolution")
-    return conv16(pool, f, [x], want32=True)
+    return conv16(pool, f, [x], act=act, want32=True)
 
 
 def hip_head(f, x):
@@ -208,34 +209,38 @@ class MultiBasicEncoder(nn.Module):
         from core.update import _X
         return bool(x.is_cuda and _hip_trunk() and self.norm_fn == "none" and self.conv1.stride == (1, 1) and "noext16" not in _X)
 
-    def trunk16(self, x) -> "s16.S16":
-        """Stem + layer1..3 on pre-split tensors (`none` norm): the stem writes S16 and every residual block stays S16."""
+    def trunk16(self, x, right=None, raw_images=False) -> "s16.S16":
+        """Stem + layer1..3 on pre-split tensors (`none` norm): the stem writes S16 and every residual block stays S16.
+        `right`: a second image batch appended to `x` along the batch inside the stem (no torch.cat); `raw_images`: 0..255 inputs,
+        normalised to [-1, 1] by the stem's input staging (tc_stereo.py:101-107)."""
         from core.update import conv32to16, pool_of
         pool = pool_of(self)
-        x = conv32to16(pool, self.conv1, x.float().contiguous(), act="relu")                       # 7x7 stem, S16 epilogue
+        x = conv32to16(pool, self.conv1, x.float().contiguous(), act="relu", image_pair=right, in_transform=int(raw_images))   # 7x7 stem, S16 epilogue
         for layer in (self.layer1, self.layer2, self.layer3):
             for blk in layer:
                 x = blk.run16(pool, x)
         return x
 
-    def heads16(self, x: "s16.S16", dual_inp, num_layers):
+    def heads16(self, x: "s16.S16", dual_inp, num_layers, relu_context=False):
         """The per-scale heads on the S16 trunk; only their final convolutions produce fp32.  With `dual_inp` the trunk holds
-        left and right images (batch-major) and the heads read the left half."""
+        left and right images (batch-major) and the heads read the left half.  `relu_context`: the second head of each scale (the
+        context features) comes out ReLU'd, which is what TCStereo.forward applies to it next (tc_stereo.py:148)."""
         from core.update import pool_of
         pool = pool_of(self)
         if dual_inp:
             x = s16.S16(x.data[: x.B // 2], x.C)
-        scales = [[hip_head16(pool, f, x) for f in self.outputs08]]
+        acts = lambda heads: [("relu" if (relu_context and j == 1) else "none") for j in range(len(heads))]
+        scales = [[hip_head16(pool, f, x, a) for f, a in zip(self.outputs08, acts(self.outputs08))]]
         if num_layers >= 2:
             y = x
             for blk in self.layer4:
                 y = blk.run16(pool, y)
-            scales.append([hip_head16(pool, f, y) for f in self.outputs16])
+            scales.append([hip_head16(pool, f, y, a) for f, a in zip(self.outputs16, acts(self.outputs16))])
         if num_layers >= 3:
             z = y
             for blk in self.layer5:
                 z = blk.run16(pool, z)
-            scales.append([hip_head16(pool, f, z) for f in self.outputs32])
+            scales.append([hip_head16(pool, f, z, a) for f, a in zip(self.outputs32, acts(self.outputs32))])
         return scales
 
     def forward(self, x, dual_inp=False, num_layers=3):

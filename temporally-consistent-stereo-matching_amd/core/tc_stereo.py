@@ -66,6 +66,14 @@ class TCStereo(nn.Module):
             if isinstance(m, nn.BatchNorm2d):
                 m.eval()
 
+    def _coords0(self, img):
+        """The x-coordinate grid at feature resolution, built once per shape (a constant of the frame)."""
+        key = (int(img.shape[0]), int(img.shape[2]), int(img.shape[3]), str(img.device))
+        cache = self.__dict__.setdefault("_coords0_cache", {})
+        if key not in cache:
+            cache[key] = coords_grid(key[0], key[1], key[2], device=img.device)[:, :1].contiguous()
+        return cache[key]
+
     def initialize_flow(self, img):
         """coords0, coords1: the x-coordinate grid at feature resolution, [N,1,H,W] each (tc_stereo.py:66-73)."""
         n, _, h, w = img.shape
@@ -152,26 +160,25 @@ class TCStereo(nn.Module):
         """Everything of a frame that depends only on its two images (tensors in, tensors out; capturable): matching features,
         correlation pyramid (+ the arg-max prior on a first frame), per-scale context terms (tc_stereo.py:101-116,147-149)."""
         a = self.args
-        image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
-        image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
 
         def correlate(fmap1, fmap2):
             corr_fn = CorrBlock1D(fmap1, fmap2, radius=a.corr_radius, num_levels=a.corr_levels, thres=a.init_thres, want_argmax=first)
             return corr_fn, (corr_fn.argmax_disp() if first else None)
 
-        def context(cnet_list):
-            """Per-scale context terms of the GRUs and of the gradient predictor (tc_stereo.py:151-156): once per frame."""
-            inp = [torch.relu(x[1]) for x in cnet_list]
+        def context(cnet_list, relu_done=False):
+            """Per-scale context terms of the GRUs and of the gradient predictor (tc_stereo.py:151-156): once per frame.  cz | cr | cq
+            stay the three thirds of the context convolution's output (channel-slice views; the GRU epilogues index them in place)."""
+            inp = [x[1] if relu_done else torch.relu(x[1]) for x in cnet_list]
             grads = [hip_conv(conv, [i]) for i, conv in zip(inp, self.context_zqr_convs_grad)]
-            zqr = [[c.contiguous() for c in hip_conv(conv, [i]).chunk(3, 1)] for i, conv in zip(inp, self.context_zqr_convs)]
+            zqr = [list(hip_conv(conv, [i]).chunk(3, 1)) for i, conv in zip(inp, self.context_zqr_convs)]
             return zqr, grads, [x[0] for x in cnet_list]
 
-        both = torch.cat((image1, image2), 0)
-        if a.shared_backbone and self.cnet.can16(both):
+        if a.shared_backbone and self.cnet.can16(image1):
             # the matching side (feature head -> correlation build) and the context side (per-scale heads -> context convolutions)
-            # both start from the shared trunk: parallel graph branches
+            # both start from the shared trunk: parallel graph branches.  The 7x7 stem reads the raw left | right images: the
+            # normalisation to [-1, 1] and the batch concatenation (tc_stereo.py:101-107) happen in its input staging.
             from tcs_mi355.streams import fork_join
-            trunk = self.cnet.trunk16(both)
+            trunk = self.cnet.trunk16(image1, right=image2, raw_images=True)
 
             def matching_side():
                 fm = hip_head(self.conv2, trunk)
@@ -179,8 +186,10 @@ class TCStereo(nn.Module):
                 return f1, f2, correlate(f1, f2)
 
             (fmap1, fmap2, (corr_fn, prior)), (inp_list, grad_list, net_list) = fork_join(
-                [matching_side, lambda: context(self.cnet.heads16(trunk, True, a.n_gru_layers))], site="frame")
+                [matching_side, lambda: context(self.cnet.heads16(trunk, True, a.n_gru_layers, relu_context=True), relu_done=True)], site="frame")
         else:
+            image1 = (2 * (image1 / 255.0) - 1.0).contiguous()
+            image2 = (2 * (image2 / 255.0) - 1.0).contiguous()
             cnet_list, fmap1, fmap2 = self._features(image1, image2)
             corr_fn, prior = correlate(fmap1, fmap2)
             inp_list, grad_list, net_list = context(cnet_list)
@@ -205,7 +214,7 @@ class TCStereo(nn.Module):
                 (-last_disp).float().contiguous(), last_fmap1.float().contiguous(), relative_T, K_scale,
                 K_scale_inv, baseline, cur_fmap=fmap1, want_fmap=False)
 
-        disp_init, _, _, net_list = self.disp_completor(sparse_disp, cost, sparse_mask, net_list)
+        disp_init, _, _, net_list = self.disp_completor(sparse_disp, cost, sparse_mask, net_list, tanh_nets=True)
         disp_init = disp_init.float().contiguous()
 
         if last_net_list is None:
@@ -218,9 +227,9 @@ class TCStereo(nn.Module):
                 if i + 1 < len(last_net_list):
                     grid = ops.grid_halve(grid)
 
-        net_list = self.fuse_previous_current_hidden_state([torch.tanh(x) for x in net_list], warped)
+        net_list = self.fuse_previous_current_hidden_state(net_list, warped)       # (tanh applied by the completor's last convolutions)
 
-        coords0, coords1 = self.initialize_flow(fmap1)
+        coords0 = self._coords0(fmap1)
         coords1 = (coords0 - disp_init).contiguous()
         trace = getattr(self, "_trace", None)          # debugging hook (eager mode only): intermediate tensors
         if trace is not None:
@@ -243,6 +252,7 @@ class TCStereo(nn.Module):
         motion = pool.get(("frame", "motion"), coords1.shape[0], 128, coords1.shape[2], coords1.shape[3], coords1.device)
         s16.set_channel(flows_x, motion, 127)
         ub = self.update_block
+        ub.begin_frame()
         from tcs_mi355.streams import fork_join, join, spawn
         hu_delta = None              # the hidden-state update of iteration i-1 runs at the head of iteration i's coarse branch
         early32 = None               # gru32 of iteration i, launched during iteration i-1 (it needs only net16 / net32)

@@ -155,11 +155,14 @@ def conv16(pool, conv, srcs, act="none", addend=None, post_scale=1.0, out=None, 
                       addend16=addend16)[0]
 
 
-def conv32to16(pool, conv, x, act="none", tag="o"):
-    """A Conv2d fed by a fp32 NCHW tensor (correlation features, disparity stencils, single-channel maps) writing S16."""
+def conv32to16(pool, conv, x, act="none", tag="o", image_pair=None, in_transform=0):
+    """A Conv2d fed by a fp32 NCHW tensor (correlation features, disparity stencils, single-channel maps) writing S16.
+    `image_pair` / `in_transform`: the 7x7 RGB stem reading raw left | right images (ops.conv2d)."""
     B, _, H, W = (int(v) for v in x.shape)
+    B += 0 if image_pair is None else int(image_pair.shape[0])
     out = pool.get((id(conv), tag), B, conv.out_channels, H, W, x.device)
-    return ops.conv2d(packed(conv), [x.float().contiguous()], act=act, out16=out)
+    return ops.conv2d(packed(conv), [x.float().contiguous()], act=act, out16=out,
+                      image_pair=None if image_pair is None else image_pair.float().contiguous(), in_transform=in_transform)
 
 
 def to16(pool, x, key):
@@ -269,13 +272,18 @@ class _GateCell(nn.Module):
         return ops.gru_update(packed(self.convq), [rh, *xs], h, z, cq, keep_z=self.keep_z)
 
     def step16(self, pool, h: s16.S16, xs, cz=None, cr=None, cq=None) -> s16.S16:
-        """The same cell on S16 tensors, updating `h` IN PLACE (two launches; z stays fp32, r*h is an S16 temporary)."""
+        """The same cell on S16 tensors, updating `h` IN PLACE (two launches; z stays fp32, r*h is an S16 temporary).  cz / cr / cq may
+        be channel slices (views) of one [B, 3*hidden, H, W] tensor — the context convolution's output, no chunk copies."""
         z = pool.get32((id(self), "z"), (h.B, h.C, h.H, h.W), h.device)
         rh = pool.get((id(self), "rh"), h.B, h.C, h.H, h.W, h.device)
+        ctot = lambda t: 0 if (t is None or t.is_contiguous()) else int(t.stride(0)) // (h.H * h.W)
         big = h.H * h.W >= 10000 and self.convzr.kernel_size[0] == 3
-        s16.gru_gates(packed16(self.convzr), [h, *xs], h, cz, cr, z_out=z, rh_out=rh, tile_cfg=121812 if (big and "rpwzr" in _X) else 0)
+        if ctot(cz) != ctot(cr):
+            cz, cr = cz.contiguous(), cr.contiguous()
+        s16.gru_gates(packed16(self.convzr), [h, *xs], h, cz, cr, z_out=z, rh_out=rh, tile_cfg=121812 if (big and "rpwzr" in _X) else 0,
+                      addend_ctot=ctot(cz))
         return s16.gru_update(packed16(self.convq), [rh, *xs], h, z, cq, keep_z=self.keep_z, out=h,
-                              tile_cfg=121812 if (big and "rpwq" in _X) else 0)
+                              tile_cfg=121812 if (big and "rpwq" in _X) else 0, addend_ctot=ctot(cq))
 
 
 class ConvGRU(_GateCell):
@@ -441,6 +449,12 @@ class BasicMultiUpdateBlock(nn.Module):
             motion_out.copy_(motion.float())
         return (out, res) if update else out
 
+    def begin_frame(self):
+        """Called once per frame before the loop: drops what `gru16_early` keeps across the iterations of ONE frame (cat(cz, cr)).
+        (The cache used to be keyed on the identity of the context tensors — which is the same object frame after frame once the
+        extract stage's outputs are static graph tensors.)"""
+        self._czr16_src = None
+
     def run_gru32(self, pool, net, inp):
         """gru32 on pool2x(net16) (update.py:147-148), in place, and interp(net32 -> 1/8 grid) for gru16.  Needs only net16 /
         net32, so the frame loop launches it for iteration i+1 as soon as gru16 of iteration i is done (tc_stereo.py)."""
@@ -455,14 +469,23 @@ class BasicMultiUpdateBlock(nn.Module):
     def gru16_early(self, pool, net, inp, up32):
         g, h = self.gru16, net[1]
         hid, c0 = h.C, h.C + net[0].C                  # c0: first input channel of interp(net32)
-        czr = pool.get32((id(self), "czr16"), (h.B, 2 * hid, h.H, h.W), h.device)
-        if getattr(self, "_czr16_src", None) is not inp[1][0]:           # cat(cz, cr): once per frame (inp is per frame)
-            torch.cat([inp[1][0], inp[1][1]], 1, out=czr)
-            self._czr16_src = inp[1][0]
+        cz, cr, cq = inp[1]
         p_zr = pool.get32((id(self), "p16zr"), (h.B, 2 * hid, h.H, h.W), h.device)
         p_q = pool.get32((id(self), "p16q"), (h.B, hid, h.H, h.W), h.device)
+        sliced = cr.data_ptr() == cz.data_ptr() + hid * h.H * h.W * 4 and cq.data_ptr() == cr.data_ptr() + hid * h.H * h.W * 4 \
+            and cz.stride(0) == cr.stride(0) == cq.stride(0) == 3 * hid * h.H * h.W
+        if sliced:                               # cz | cr | cq are the three thirds of the context convolution's output: cat(cz, cr) is a view
+            ct = int(cz.stride(0)) // (h.H * h.W)
+            czr = torch.as_strided(cz, (h.B, 2 * hid, h.H, h.W), cz.stride())
+            s16.conv2d(packed16_part(g.convzr, ((0, hid), (c0, c0 + up32.C))), [h, up32], addend=czr, addend_ctot=ct, out32=p_zr)
+            s16.conv2d(packed16_part(g.convq, ((c0, c0 + up32.C),)), [up32], addend=cq, addend_ctot=ct, out32=p_q)
+            return p_zr, p_q
+        czr = pool.get32((id(self), "czr16"), (h.B, 2 * hid, h.H, h.W), h.device)
+        if getattr(self, "_czr16_src", None) is not cz:                  # cat(cz, cr): once per frame (inp is per frame)
+            torch.cat([cz, cr], 1, out=czr)
+            self._czr16_src = cz
         s16.conv2d(packed16_part(g.convzr, ((0, hid), (c0, c0 + up32.C))), [h, up32], addend=czr, out32=p_zr)
-        s16.conv2d(packed16_part(g.convq, ((c0, c0 + up32.C),)), [up32], addend=inp[1][2], out32=p_q)
+        s16.conv2d(packed16_part(g.convq, ((c0, c0 + up32.C),)), [up32], addend=cq.contiguous(), out32=p_q)
         return p_zr, p_q
 
     def gru16_late(self, pool, net, partial):
@@ -735,11 +758,11 @@ class DisparityCompletor(nn.Module):
         self.conv_out8_disp = cin_block(192, 192, 128)
         self.conv_out4_disp = cin_block(192, 192, 128)
 
-    def _cin(self, seq, srcs):
+    def _cin(self, seq, srcs, act="none"):
         """conv -> InstanceNorm -> ReLU -> conv blocks (update.py:325-367)."""
-        return hip_conv(seq[3], [ops.instance_norm(hip_conv(seq[0], srcs), act="relu")])
+        return hip_conv(seq[3], [ops.instance_norm(hip_conv(seq[0], srcs), act="relu")], act=act)
 
-    def _forward_hip(self, disp, cost, mask, ctx):
+    def _forward_hip(self, disp, cost, mask, ctx, tanh_nets=False):
         d = (disp / 10).float().contiguous()
         stems = [hip_seq(self.conv_disp_stem, [d]), hip_seq(self.conv_cost_stem, [cost.float().contiguous()]),
                  hip_seq(self.conv_mask_stem, [(mask - 0.5).float().contiguous()])]
@@ -752,11 +775,14 @@ class DisparityCompletor(nn.Module):
         disp_mono = hip_seq(self.disp_head, [x4_out])
         w = hip_conv(self.w_head[2], [hip_conv(self.w_head[0], [x4_out], act="relu")], act="sigmoid")
         completed = (w * d + (1 - w) * disp_mono) * 10
-        nets = [self._cin(self.conv_out4_disp, [x4_out, ctx[0]]), self._cin(self.conv_out8_disp, [x8_out, ctx[1]]),
-                self._cin(self.conv_out16_disp, [x16_out, ctx[2]])]
+        na = "tanh" if tanh_nets else "none"                # the caller's torch.tanh (tc_stereo.py:167) in the last convolutions' epilogues
+        nets = [self._cin(self.conv_out4_disp, [x4_out, ctx[0]], na), self._cin(self.conv_out8_disp, [x8_out, ctx[1]], na),
+                self._cin(self.conv_out16_disp, [x16_out, ctx[2]], na)]
         return completed, disp_mono * 10, w, nets
 
-    def forward(self, disp, cost, mask, context_list):
+    def forward(self, disp, cost, mask, context_list, tanh_nets=False):
+        """`tanh_nets` (not in the reference's signature): return tanh of the three new hidden states, which is what
+        TCStereo.forward applies to them next (tc_stereo.py:167)."""
         if not disp.is_cuda:
             raise RuntimeError("DisparityCompletor: CPU tensor (the hot path has no CPU fallback)")
-        return self._forward_hip(disp, cost, mask, [c.float().contiguous() for c in context_list])
+        return self._forward_hip(disp, cost, mask, [c.float().contiguous() for c in context_list], tanh_nets)

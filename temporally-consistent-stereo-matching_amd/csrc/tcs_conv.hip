@@ -233,13 +233,16 @@ __global__ __launch_bounds__(256) void k_conv7x7(ConvArgs a) {
     const int ntx = (W + TW - 1) / TW;
     const int tx0 = (blockIdx.x % ntx) * TW, ty0 = (blockIdx.x / ntx) * TH;
     const int co_lo = blockIdx.z * NC;
-    const float* s = a.src[0] + (size_t)b * CIN * HW;
+    // RGB stem: the left | right batch concatenation and the image normalisation of tc_stereo.py:101-107 happen here
+    const float* s = (CIN == 3 && a.src_b2 && b >= a.b_split) ? a.src_b2 + (size_t)(b - a.b_split) * CIN * HW : a.src[0] + (size_t)b * CIN * HW;
+    const bool norm = CIN == 3 && a.in_transform == 1;
     for (int i = threadIdx.x; i < CIN * IH * IW; i += 256) {
         const int ci = i / (IH * IW), q = i - ci * (IH * IW);
         const int r = q / IW, c = q - r * IW;
         const int yy = ty0 - HALO + r, xx = tx0 - HALO + c;
         const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-        const float v = s[(size_t)ci * HW + min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)];
+        float v = s[(size_t)ci * HW + min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)];
+        if (norm) v = 2.0f * (v / 255.0f) - 1.0f;           // the reference's own arithmetic (x2 is exact, so a fused multiply-add changes nothing)
         s_in[i] = ok ? v : 0.f;
     }
     __syncthreads();
@@ -359,6 +362,12 @@ int tcs_conv2d(const tcs_conv_desc* d, tcs_stream_t stream) {
     a.keep_z = d->blend_keep_z; a.hidden = 0;
     a.out = d->out; a.out_ctot = d->out_ctot; a.out_coff = d->out_coff; a.out2 = d->out2;
     a.out16 = reinterpret_cast<_Float16*>(d->out16); a.out16_groups = d->out16_groups; a.out16_goff = d->out16_group_offset;
+    a.in_transform = d->in_transform; a.src_b2 = d->src_batch2; a.b_split = d->batch_split;
+    if (a.in_transform || a.src_b2) {                   // honoured by the 7x7 RGB stem only
+        if (d->ksize != 7 || d->Cin != 3 || d->n_src != 1 || d->math != TCS_MATH_F32 || d->epilogue != TCS_EPI_LINEAR) return TCS_EUNSUPPORTED;
+        if (a.in_transform != 0 && a.in_transform != 1) return TCS_EINVAL;
+        if (a.src_b2 && (a.b_split <= 0 || a.b_split >= d->B)) return TCS_EINVAL;
+    }
     a.npx = tcs_cdiv(d->W, 32);
     a.npatch = a.npx * tcs_cdiv(d->H, 4);
     a.nct = a.CoutPad / nt;

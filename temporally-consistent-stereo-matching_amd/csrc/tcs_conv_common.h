@@ -30,6 +30,9 @@ struct ConvArgs {
     float w_unscale;        // fp16-split kernel: 2^-s undoing the weight pre-scale (1 for the fp32 kernel)
     _Float16* out16;        // LINEAR: optional S16 copy of the output (tcs_s16.h), written at group offset out16_goff
     int out16_groups, out16_goff;
+    int in_transform;       // k_conv7x7<3>: 1 = samples are read as 2 * (x / 255) - 1 (tc_stereo.py:101-102)
+    const float* src_b2;    // k_conv7x7<3>: batch elements >= b_split come from this tensor
+    int b_split;
 };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }

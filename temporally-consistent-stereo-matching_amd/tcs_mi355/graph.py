@@ -19,10 +19,15 @@ lets the host enqueue frame t+1 while frame t runs.
 """
 from __future__ import annotations
 
+import os
 import warnings
 from typing import Callable, Dict, List, Optional
 
 import torch
+
+# A/B switches (TCS_MI355_X tokens, never set in production): "xlow" = the extract stream at low priority, "rhigh" = the refine stage
+# replayed on a high-priority stream
+_X = set(t for t in os.environ.get("TCS_MI355_X", "").split(",") if t)
 
 
 def _flatten(temporal):
@@ -113,7 +118,15 @@ class FrameGraphs:
     def _stream(self, device) -> torch.cuda.Stream:
         st = self._sx.get(device)
         if st is None:
-            st = self._sx[device] = torch.cuda.Stream(device=device)
+            st = self._sx[device] = torch.cuda.Stream(device=device, priority=1 if "xlow" in _X else 0)
+        return st
+
+    def _refine_stream(self, device):
+        if "rhigh" not in _X:
+            return None
+        st = self._sx.get((device, "hp"))
+        if st is None:
+            st = self._sx[(device, "hp")] = torch.cuda.Stream(device=device, priority=-1)
         return st
 
     @staticmethod
@@ -263,7 +276,14 @@ class FrameGraphs:
             e = entries[si]
             for dst, src in zip(e.static_in, flat):
                 dst.copy_(src)
-            e.graph.replay()
+            hp = self._refine_stream(image1.device)
+            if hp is not None:
+                hp.wait_stream(main)
+                with torch.cuda.stream(hp):
+                    e.graph.replay()
+                main.wait_stream(hp)
+            else:
+                e.graph.replay()
             o = e.static_out
             out = {"flow": o["flow"].clone(), "flow_q": o["flow_q"].clone(), "net_list": [t.clone() for t in o["net_list"]],
                    "fmap1": o["fmap1"].clone()}

@@ -36,6 +36,7 @@ class ConvDesc(C.Structure):
         ("out", c_fp), ("out_ctot", c_int), ("out_coff", c_int), ("out2", c_fp),
         ("stride", c_int), ("math", c_int), ("weight_unscale", c_f),
         ("out16", c_fp), ("out16_groups", c_int), ("out16_group_offset", c_int),
+        ("in_transform", c_int), ("src_batch2", c_fp), ("batch_split", c_int),
     ]
 
 

@@ -416,10 +416,18 @@ def _desc(pc: PackedConv, srcs: Sequence[torch.Tensor]) -> nv.ConvDesc:
 
 
 def conv2d(pc: PackedConv, srcs: Sequence[torch.Tensor], act: str = "none", addend=None, post_scale: float = 1.0,
-           out: Optional[torch.Tensor] = None, out_coff: int = 0, stride: int = 1, out16=None, out16_group_offset: int = 0):
+           out: Optional[torch.Tensor] = None, out_coff: int = 0, stride: int = 1, out16=None, out16_group_offset: int = 0,
+           image_pair: Optional[torch.Tensor] = None, in_transform: int = 0):
     """`out16` (a tcs_mi355.s16.S16): write the result in pre-split form for tcs_conv2d_s16 consumers INSTEAD of fp32 NCHW
-    (returns out16); stride 1 only."""
+    (returns out16); stride 1 only.  7x7 RGB stem only: `image_pair` = the right images, appended to srcs[0] along the batch
+    (torch.cat((image1, image2), 0) without the copy), `in_transform=1` = samples read as 2 * (x / 255) - 1 (tc_stereo.py:101-107)."""
     d = _desc(pc, srcs)
+    if image_pair is not None:
+        if len(srcs) != 1 or tuple(image_pair.shape[1:]) != tuple(srcs[0].shape[1:]):
+            raise ValueError("conv2d: `image_pair` must match the single source's [C,H,W]")
+        d.src_batch2, d.batch_split = nv.ptr(image_pair, "image_pair"), d.B
+        d.B = d.B + int(image_pair.shape[0])
+    d.in_transform = int(in_transform)
     if out16 is not None:
         if stride != 1 or (out16.B, out16.H, out16.W) != (d.B, d.H, d.W):
             raise ValueError("conv2d: bad `out16`")

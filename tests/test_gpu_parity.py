@@ -535,8 +535,7 @@ def test_graph_replay_matches_eager(dev, model):
     assert model._graphs is not None and model._graphs.fell_back == 0 and all(v is not None for v in model._graphs.cache.values()), \
         "capture fell back to eager"
     for t in range(3):
-        # not bit-identical: MIOpen may choose another algorithm for the extractor convs under capture, and the
-        # splat's float atomics commit in a different order from run to run
+        # not bit-identical on temporal frames: the splat's float atomics commit in a different order from run to run
         assert epe(graphed[t], eager[t]) <= 1e-5 and epe(again[t], eager[t]) <= 1e-5, t
 
 
@@ -777,7 +776,7 @@ def test_batched_sequences_match_single(dev, model):
 
 
 def test_stride2_deconv_instancenorm_vs_torch(dev):
-    """The U-Net pieces moved off MIOpen: 3x3 stride-2 conv, ConvTranspose2d(4,2,1), InstanceNorm (+act, +addend)."""
+    """The U-Net pieces on the fp32-tensor kernels: 3x3 stride-2 conv, ConvTranspose2d(4,2,1), InstanceNorm (+act, +addend)."""
     from tcs_mi355 import ops
     gen = torch.Generator().manual_seed(21)
     for (cin, cout, H, W) in ((64, 96, 120, 160), (96, 128, 60, 80), (40, 33, 9, 21)):
@@ -801,3 +800,24 @@ def test_stride2_deconv_instancenorm_vs_torch(dev):
     assert maxdiff(ops.instance_norm(D(x, dev), act="leaky", addend=D(add, dev)),
                    F.leaky_relu(F.instance_norm(x.double()), 0.01) + add.double()) <= 1e-5
     assert maxdiff(ops.instance_norm(D(x, dev), act="relu"), F.relu(F.instance_norm(x.double()))) <= 1e-5
+
+
+def test_rgb_stem_reads_raw_image_pairs(dev):
+    """tcs_conv_desc.in_transform / src_batch2: the 7x7 RGB stem normalises 0..255 images to [-1, 1] and appends the right images to the
+    left ones along the batch inside its input staging (tc_stereo.py:101-107) — same arithmetic as torch's 2 * (x / 255) - 1 and
+    torch.cat, so the result equals the stem on the prepared batch exactly."""
+    from tcs_mi355 import ops
+    gen = torch.Generator().manual_seed(41)
+    l = torch.randint(0, 256, (2, 3, 37, 70), generator=gen).float()
+    r = torch.randint(0, 256, (2, 3, 37, 70), generator=gen).float()
+    w = torch.randn(64, 3, 7, 7, generator=gen) * 0.1
+    b = torch.randn(64, generator=gen) * 0.1
+    pc = ops.pack_conv(D(w, dev), D(b, dev), "f32")
+    both = torch.cat((2 * (D(l, dev) / 255.0) - 1.0, 2 * (D(r, dev) / 255.0) - 1.0), 0).contiguous()
+    want = ops.conv2d(pc, [both], act="relu")
+    got = ops.conv2d(pc, [D(l, dev)], act="relu", image_pair=D(r, dev), in_transform=1)
+    assert tuple(got.shape) == (4, 64, 37, 70) and torch.equal(got, want)
+    ref = F.relu(F.conv2d(both.double().cpu(), w.double(), b.double(), padding=3))
+    assert maxdiff(got, ref) <= 2e-5
+    with pytest.raises(RuntimeError):                      # only the RGB stem honours it
+        ops.conv2d(ops.pack_conv(D(torch.randn(8, 4, 3, 3), dev), None, "f32"), [D(torch.randn(1, 4, 8, 32), dev)], in_transform=1)
