@@ -25,8 +25,8 @@ from typing import Callable, Dict, List, Optional
 
 import torch
 
-# A/B switches (TCS_MI355_X tokens, never set in production): "xlow" = the extract stream at low priority, "rhigh" = the refine stage
-# replayed on a high-priority stream
+# A/B switch (TCS_MI355_X token, never set in production): "xlow" = the extract stream at low priority.  (Replaying the refine stage on a
+# high-priority stream instead doubled the frame time on ROCm 7.2: 28 -> 58 ms; removed.)
 _X = set(t for t in os.environ.get("TCS_MI355_X", "").split(",") if t)
 
 
@@ -68,6 +68,8 @@ class _Slot:
     def __init__(self):
         self.feats = None
         self.token = None                      # identifies the images (and mode) the features belong to
+        self.fresh = False                     # features nobody has consumed yet
+        self.by_prefetch = False
         self.ex_key = None
         self.ready = torch.cuda.Event()        # EXTRACT done (recorded on the extract stream)
         self.free = torch.cuda.Event()         # the REFINE that read the features is done (recorded on the caller's stream)
@@ -90,8 +92,7 @@ class FrameGraphs:
                  strict: bool = False):
         self.extract_fn, self.refine_fn, self.warmup, self.epoch_fn, self.strict = extract_fn, refine_fn, warmup, epoch_fn, strict
         self.slots = [_Slot(), _Slot()]
-        self.turn = 0                          # the slot the next EXTRACT goes to
-        self.pending: Optional[int] = None     # slot of a prefetch nobody has consumed yet
+        self.turn = 0                          # the slot the next EXTRACT goes to (unless it still holds unconsumed features)
         self.ex: Dict[tuple, Optional[List[_Entry]]] = {}
         self.rf: Dict[tuple, Optional[List[_Entry]]] = {}
         self.epoch = epoch_fn() if epoch_fn is not None else None
@@ -113,7 +114,7 @@ class FrameGraphs:
                 self.ex.clear()
                 self.rf.clear()
                 self.slots = [_Slot(), _Slot()]
-                self.pending, self.turn, self.epoch = None, 0, now
+                self.turn, self.epoch = 0, now
 
     def _stream(self, device) -> torch.cuda.Stream:
         st = self._sx.get(device)
@@ -121,13 +122,13 @@ class FrameGraphs:
             st = self._sx[device] = torch.cuda.Stream(device=device, priority=1 if "xlow" in _X else 0)
         return st
 
-    def _refine_stream(self, device):
-        if "rhigh" not in _X:
-            return None
-        st = self._sx.get((device, "hp"))
-        if st is None:
-            st = self._sx[(device, "hp")] = torch.cuda.Stream(device=device, priority=-1)
-        return st
+    def _pick_slot(self) -> int:
+        """Where the next EXTRACT goes: the slot whose features have been consumed (a prefetch made for the NEXT frame must survive
+        the call for the current one); with two unconsumed sets, the older."""
+        for k in (self.turn, self.turn ^ 1):
+            if not self.slots[k].fresh:
+                return k
+        return self.turn
 
     @staticmethod
     def _token(image1, image2, first, use_graph):
@@ -198,16 +199,20 @@ class FrameGraphs:
                 for t in _tensors(slot.feats):       # allocated on the extract stream, read on the caller's: keep the blocks alive for it
                     t.record_stream(main)
             slot.ready.record(sx)
-        slot.token, slot.ex_key = self._token(image1, image2, first, use_graph), key
+        slot.token, slot.ex_key, slot.fresh, slot.by_prefetch = self._token(image1, image2, first, use_graph), key, True, False
+        self.turn = si ^ 1
 
     def prefetch(self, image1, image2, first: bool = False, use_graph: bool = True) -> int:
         """Launch the EXTRACT stage of a coming frame now (beside whatever the GPU is still doing); the next `__call__` with the same
         image tensors (same storage, unmodified) uses it.  Call it BEFORE the `__call__` it is to overlap with.  Returns the slot."""
         self._check_epoch()
-        si = self.pending if self.pending is not None else self.turn      # an unused prefetch is simply replaced
+        token = self._token(image1, image2, first, use_graph)
+        for k in (0, 1):
+            if self.slots[k].fresh and self.slots[k].token == token:
+                return k                                    # already there
+        si = self._pick_slot()
         self._launch_extract(si, image1, image2, first, use_graph)
-        self.pending = si
-        self.turn = si ^ 1
+        self.slots[si].by_prefetch = True
         return si
 
     # ---- REFINE --------------------------------------------------------------------------------------------------------------
@@ -240,6 +245,8 @@ class FrameGraphs:
                 entries.append(_Entry(g, static_in, out))
             torch.cuda.synchronize()
             self.captures += 1
+            for sl in self.slots:                       # the capture used both slots: whatever was prefetched into them is gone
+                sl.fresh, sl.token = False, None
             return entries
         except Exception as e:
             if self.strict:
@@ -261,29 +268,21 @@ class FrameGraphs:
             entries = self.rf[key]
             if entries is None:
                 self.fell_back += 1
-        if self.pending is not None and self.slots[self.pending].token == token:
-            si = self.pending
-            self.prefetched += 1
+        si = next((k for k in (0, 1) if self.slots[k].fresh and self.slots[k].token == token), None)
+        if si is not None:
+            self.prefetched += int(self.slots[si].by_prefetch)
         else:
-            si = self.pending if self.pending is not None else self.turn
+            si = self._pick_slot()
             self._launch_extract(si, image1, image2, first, use_graph and entries is not None)
-            self.turn = si ^ 1
-        self.pending = None
         slot = self.slots[si]
+        slot.fresh = False
         main = torch.cuda.current_stream()
         main.wait_event(slot.ready)
         if entries is not None and self.ex.get(slot.ex_key) is not None and slot.feats is self.ex[slot.ex_key][si].static_out:
             e = entries[si]
             for dst, src in zip(e.static_in, flat):
                 dst.copy_(src)
-            hp = self._refine_stream(image1.device)
-            if hp is not None:
-                hp.wait_stream(main)
-                with torch.cuda.stream(hp):
-                    e.graph.replay()
-                main.wait_stream(hp)
-            else:
-                e.graph.replay()
+            e.graph.replay()
             o = e.static_out
             out = {"flow": o["flow"].clone(), "flow_q": o["flow_q"].clone(), "net_list": [t.clone() for t in o["net_list"]],
                    "fmap1": o["fmap1"].clone()}
