@@ -188,17 +188,23 @@ def lookup_roofline(probe, snapshots, burst, pixels):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 pmc = json.load(f)
-            if pmc.get("algorithmic_bytes_per_launch") == alg_bytes:
+            rows = list(pmc.get("workloads", {}).items()) or [("", pmc)]
+            hit = next(((k, r) for k, r in rows if r.get("algorithmic_bytes_per_launch") == alg_bytes), None)
+            if hit is None:
+                continue
+            key, row = hit
+            if pmc.get("algorithmic_bytes_per_launch") == alg_bytes and "traffic_bytes_per_launch" in pmc:
                 roof["traffic"] = pmc["traffic_bytes_per_launch"]
                 roof["traffic_source"] = f"profiles/{name} (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc passes)"
-                for key in ("rocprof_burst_avg_us", "rocprof_loop_avg_us", "rocprof_kernel_trace_avg_us"):
-                    if key in pmc:
-                        roof[key] = pmc[key]
-                rp = pmc.get("rocprof_loop_avg_us") or pmc.get("rocprof_burst_avg_us") or pmc.get("rocprof_kernel_trace_avg_us")
-                if rp:
-                    roof["frac_rocprof"] = frac(rp)
-                    roof["frac_rocprof_source"] = f"profiles/{name}: rocprofv3 --kernel-trace average of the frame's own lookup launches"
-                break
+            for k in ("rocprof_burst_avg_us", "rocprof_loop_avg_us", "rocprof_kernel_trace_avg_us"):
+                if k in row:
+                    roof[k] = row[k]
+            rp = row.get("rocprof_loop_avg_us") or row.get("rocprof_burst_avg_us") or row.get("rocprof_kernel_trace_avg_us")
+            if rp:
+                roof["frac_rocprof"] = frac(rp)
+                roof["frac_rocprof_source"] = (f"profiles/{name}" + (f" [{key}]" if key else "") +
+                                               ": rocprofv3 --kernel-trace average of the frame's own lookup launches")
+            break
         except (OSError, KeyError, ValueError):
             continue
     return roof

@@ -132,7 +132,14 @@ class FrameGraphs:
 
     @staticmethod
     def _token(image1, image2, first, use_graph):
-        return (image1.data_ptr(), image1._version, image2.data_ptr(), image2._version, tuple(image1.shape), bool(first), bool(use_graph))
+        """Identifies the frame a slot's features belong to: the image tensor OBJECTS (the slot keeps them alive, so their storage
+        cannot be handed to other tensors meanwhile — a data_ptr alone can come back with other content), their versions (no
+        in-place write since), the branch and the launch mode."""
+        return (image1, image1._version, image2, image2._version, bool(first), bool(use_graph))
+
+    @staticmethod
+    def _same(a, b):
+        return a is not None and b is not None and a[0] is b[0] and a[2] is b[2] and a[1] == b[1] and a[3] == b[3] and a[4:] == b[4:]
 
     @staticmethod
     def _ex_key(image1, first):
@@ -208,7 +215,7 @@ class FrameGraphs:
         self._check_epoch()
         token = self._token(image1, image2, first, use_graph)
         for k in (0, 1):
-            if self.slots[k].fresh and self.slots[k].token == token:
+            if self.slots[k].fresh and self._same(self.slots[k].token, token):
                 return k                                    # already there
         si = self._pick_slot()
         self._launch_extract(si, image1, image2, first, use_graph)
@@ -268,14 +275,14 @@ class FrameGraphs:
             entries = self.rf[key]
             if entries is None:
                 self.fell_back += 1
-        si = next((k for k in (0, 1) if self.slots[k].fresh and self.slots[k].token == token), None)
+        si = next((k for k in (0, 1) if self.slots[k].fresh and self._same(self.slots[k].token, token)), None)
         if si is not None:
             self.prefetched += int(self.slots[si].by_prefetch)
         else:
             si = self._pick_slot()
             self._launch_extract(si, image1, image2, first, use_graph and entries is not None)
         slot = self.slots[si]
-        slot.fresh = False
+        slot.fresh, slot.token = False, None            # consumed (and the image tensors are no longer held)
         main = torch.cuda.current_stream()
         main.wait_event(slot.ready)
         if entries is not None and self.ex.get(slot.ex_key) is not None and slot.feats is self.ex[slot.ex_key][si].static_out:

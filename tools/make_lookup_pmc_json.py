@@ -1,7 +1,18 @@
 #!/usr/bin/env python3
-"""profiles/rNN_lookup_pmc.json from (a) the two --pmc passes (FETCH_SIZE, WRITE_SIZE) and (b) the per-phase fold of the kernel
-trace (tools/fold_kernel_trace.py).  usage: make_lookup_pmc_json.py <pmc_fetch_dir> <pmc_write_dir> <fold.csv> <out.json>"""
-import csv, glob, json, sys
+"""profiles/rNN_lookup_pmc.json: the corr lookup's HBM traffic (two --pmc passes: FETCH_SIZE, WRITE_SIZE) and its rocprofv3 durations per
+workload, from per-phase folds of kernel traces (tools/fold_kernel_trace.py).
+
+usage: make_lookup_pmc_json.py --fetch <pmc dir> --write <pmc dir> --row <name>:<fold.csv>:<pixels per launch> [--row ...] --out <json>
+
+The FIRST row is the headline workload (BASELINE configs[1], one 640x480 sequence): its figures are also written at the top level, where
+bench.py reads `traffic_bytes_per_launch`, `algorithmic_bytes_per_launch`, `rocprof_loop_avg_us` and `rocprof_burst_avg_us`."""
+import argparse
+import csv
+import glob
+import json
+
+BYTES_PER_PIXEL = 308          # 4 levels x 10 taps x 4 B + 4 B coordinate + 36 x 4 B out
+HBM_PEAK = 8.0e12
 
 
 def pmc_mean(d, counter):
@@ -13,26 +24,48 @@ def pmc_mean(d, counter):
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
 
-fetch, nf = pmc_mean(sys.argv[1], "FETCH_SIZE")
-write, nw = pmc_mean(sys.argv[2], "WRITE_SIZE")
-rows = [r for r in csv.DictReader(open(sys.argv[3])) if "k_corr_lookup" in r["kernel"]]
-by = {r["phase"]: r for r in rows}
-triv = [r for r in csv.DictReader(open(sys.argv[3])) if r["phase"] == "loop" and any(k in r["kernel"] for k in ("k_flow_step_grads", "k_softmax_blend"))]
-out = {
-    "kernel": "k_corr_lookup<4, 1>", "launches_profiled_pmc": [nf, nw],
-    "FETCH_SIZE_KB_raw_mean": round(fetch, 1), "WRITE_SIZE_KB_mean": round(write, 1),
-    "fetch_bytes_corrected_x2": int(2 * fetch * 1024), "write_bytes": int(write * 1024),
-    "traffic_bytes_per_launch": int(2 * fetch * 1024 + write * 1024), "algorithmic_bytes_per_launch": 308 * 19200,
-    "rocprof_burst_avg_us": float(by["burst"]["avg_us"]) if "burst" in by else None,
-    "rocprof_burst_calls": int(by["burst"]["calls"]) if "burst" in by else 0,
-    "rocprof_burst_gap_before_us": float(by["burst"]["gap_before_us"]) if "burst" in by else None,
-    "rocprof_loop_avg_us": float(by["loop"]["avg_us"]) if "loop" in by else None,
-    "rocprof_loop_calls": int(by["loop"]["calls"]) if "loop" in by else 0,
-    "rocprof_trivial_kernels_in_loop_position_us": {r["kernel"][:40]: float(r["avg_us"]) for r in triv},
-    "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B; 4-B-per-lane loads are a width the "
-            "guide calls uncalibrated, so the true read traffic lies between raw and corrected; algorithmic reads 3.15 MB). "
-            "burst = launches that directly follow another lookup launch (bench.py's event-timed graph bursts), loop = launches "
-            "inside the frame graph behind a different kernel; rocprofv3's interval includes dispatch/completion overhead, see the "
-            "trivial kernels' readings in the same position."}
-json.dump(out, open(sys.argv[4], "w"), indent=1)
+def fold_row(path, pixels):
+    rows = list(csv.DictReader(open(path)))
+    by = {r["phase"]: r for r in rows if "k_corr_lookup" in r["kernel"]}
+    triv = [r for r in rows if r["phase"] == "loop" and any(k in r["kernel"] for k in ("k_flow_taps_step_grads", "k_flow_step_grads", "k_in_apply"))]
+    alg = BYTES_PER_PIXEL * pixels
+    out = {"pixels_per_launch": pixels, "algorithmic_bytes_per_launch": alg}
+    for ph in ("loop", "burst"):
+        if ph in by:
+            us = float(by[ph]["avg_us"])
+            out[f"rocprof_{ph}_avg_us"] = us
+            out[f"rocprof_{ph}_calls"] = int(by[ph]["calls"])
+            out[f"rocprof_{ph}_gap_before_us"] = float(by[ph]["gap_before_us"])
+            out[f"frac_rocprof_{ph}"] = round(alg / (us * 1e-6) / HBM_PEAK, 4)
+    out["rocprof_trivial_kernels_in_loop_position_us"] = {r["kernel"][:40]: float(r["avg_us"]) for r in triv}
+    return out
+
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--fetch")
+ap.add_argument("--write")
+ap.add_argument("--row", action="append", required=True)
+ap.add_argument("--out", required=True)
+a = ap.parse_args()
+rows = {}
+for spec in a.row:
+    name, path, pixels = spec.split(":")
+    rows[name] = fold_row(path, int(pixels))
+first = next(iter(rows.values()))
+out = {"kernel": "k_corr_lookup<4, 1>", "workloads": rows}
+out.update({k: first[k] for k in ("algorithmic_bytes_per_launch", "rocprof_loop_avg_us", "rocprof_loop_calls", "rocprof_burst_avg_us",
+                                  "rocprof_burst_calls") if k in first})
+if a.fetch and a.write:
+    fetch, nf = pmc_mean(a.fetch, "FETCH_SIZE")
+    write, nw = pmc_mean(a.write, "WRITE_SIZE")
+    if fetch is not None and write is not None:
+        out.update({"launches_profiled_pmc": [nf, nw], "FETCH_SIZE_KB_raw_mean": round(fetch, 1), "WRITE_SIZE_KB_mean": round(write, 1),
+                    "fetch_bytes_corrected_x2": int(2 * fetch * 1024), "write_bytes": int(write * 1024),
+                    "traffic_bytes_per_launch": int(2 * fetch * 1024 + write * 1024)})
+out["note"] = ("FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B; 4-B-per-lane loads are a width the guide calls "
+               "uncalibrated, so the true read traffic lies between raw and corrected).  loop = launches inside the frame graph behind a "
+               "different kernel, burst = launches that directly follow another lookup launch (bench.py's event-timed graph bursts); "
+               "rocprofv3's interval includes dispatch / completion overhead: see the trivial kernels' readings in the same position.  "
+               "frac_rocprof_* = algorithmic bytes / rocprofv3 average duration / 8 TB/s.")
+json.dump(out, open(a.out, "w"), indent=1)
 print(json.dumps(out, indent=1))
