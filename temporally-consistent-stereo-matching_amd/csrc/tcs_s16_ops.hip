@@ -449,10 +449,10 @@ int tcs_s16_set_channel(const float* x, int B, int H, int W, void* s16, int grou
 //
 // Weights (304 KB of A fragments per wave-pass) stream through LDS: the four waves of a workgroup share every fragment, and
 // one k-step of a four-tile pass is 8 KiB = 8 LDS-DMA instructions (global_load_lds_dwordx4, two per wave).  The 40 stages of the
-// four products (W2: 4 x 4 KiB; z, r, q: 12 x 8 KiB each) form ONE software pipeline, HU_D stages in flight across the products'
+// four products (W2: 4 x 4 KiB; z, r, q: 12 x 8 KiB each) form ONE software pipeline over HU_D stage buffers, running across the products'
 // boundaries, so the weights of the next product arrive during the activation arithmetic of the current one:
-//     wait own pieces of stage g (counted vmcnt) -> s_barrier -> refill the buffer of stage g-1 with stage g+HU_D-1 -> 2*NT
-//     ds_read_b128 -> 3*NT MFMAs.
+//     wait own pieces of stage g+1 (counted vmcnt) -> s_barrier -> refill the buffer of stage g-1 with stage g+HU_D-1 -> 2*NT
+//     ds_read_b128 of stage g+1 (into the other register set) -> wait for stage g's fragments (counted lgkmcnt) -> 3*NT MFMAs of stage g.
 // Round 2's version read the fragments per wave from L2 (310 KB per wave, 186 MB per launch through the L1s): 30 us alone,
 // 41-47 us inside the loop; deeper register prefetch changed nothing (the L1 fill rate, not latency, was the bound).
 // =====================================================================================================================
@@ -510,7 +510,7 @@ __device__ __forceinline__ float hu_tanh(float v) {
 
 #define HU_WAVES 4
 #define HU_NBIAS (64 + 64 + 64 + 256 + 128)           // w1, b1, b2, bzr, bq
-#define HU_D 4                                        // weight stages in flight
+#define HU_D 6                                        // stage buffers: one being multiplied, one being fetched into registers, HU_D - 2 in flight
 #define HU_STAGE_BYTES 8192
 #define HU_RING_OFF 4096                              // byte offset of the stage ring behind the bias table
 #define HU_NSTAGE 40                                  // W2: 0-3 (4 KiB), z: 4-15, r: 16-27, q: 28-39 (8 KiB each)
@@ -540,31 +540,50 @@ __device__ __forceinline__ float hu_tanh(float v) {
     }
 #define HU_WAITV_N(N)                                                                                                 \
     {                                                                                                                 \
-        if ((N) >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                \
+        if ((N) >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                \
+        else if ((N) == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                                           \
+        else if ((N) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                           \
         else if ((N) == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                           \
         else if ((N) == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                           \
         else if ((N) == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");                                           \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
     }
-#define HU_DSREAD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "i"(OFF) : "memory")
-// one product: NK k-steps starting at global stage G0, NT output tiles; BFRAG(s, bh, bl) yields the B operand of k-step s
-#define HU_GEMM(ACC, NT, NK, G0, BFRAG)                                                                               \
-    _Pragma("unroll") for (int s = 0; s < NK; ++s) {                                                                  \
-        /* own pieces of stage G0+s have landed; stages G0+s+1, G0+s+2 (issued earlier) may stay in flight */          \
-        HU_WAITV_N(HU_PIECES((G0) + s + 1) + HU_PIECES((G0) + s + 2))                                                 \
-        __builtin_amdgcn_s_barrier();               /* everyone's pieces landed; everyone is done with stage G0+s-1 */   \
-        HU_ISSUE((G0) + s + HU_D - 1)                                                                                 \
-        half8 ah_[NT], al_[NT];                                                                                       \
-        const unsigned ra_ = lds_ring + (unsigned)(((G0) + s) % HU_D) * HU_STAGE_BYTES + voff_lane;                   \
-        _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                              \
-            HU_DSREAD(ah_[t], ra_, (t * 2 + 0) * 1024);                                                               \
-            HU_DSREAD(al_[t], ra_, (t * 2 + 1) * 1024);                                                               \
-        }                                                                                                             \
-        half8 bh_, bl_;                                                                                               \
-        BFRAG(s, bh_, bl_)                                                                                            \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                            \
+#define HU_WAITL_N(N)                                                                                                 \
+    {                                                                                                                 \
+        if ((N) >= 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                                              \
+        else if ((N) == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                         \
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
-        _Pragma("unroll") for (int t = 0; t < NT; ++t) { HU_MMA3(ACC[t], ah_[t], al_[t], bh_, bl_) }                  \
+    }
+#define HU_DSREAD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "i"(OFF) : "memory")
+// stage G becomes readable: its own DMA pieces have landed (stages G+1 .. G+HU_D-3, issued earlier, may stay in flight), everyone's have
+// (barrier: also "everyone has finished READING stage G-2", whose buffer the next DMA overwrites), the pipeline is topped up, and the NT
+// fragment pairs of stage G start moving into registers
+#define HU_BEGIN(G, NT, AH, AL)                                                                                       \
+    {                                                                                                                 \
+        HU_WAITV_N(HU_PIECES((G) + 1) + HU_PIECES((G) + 2) + HU_PIECES((G) + 3))                                      \
+        __builtin_amdgcn_s_barrier();                                                                                 \
+        HU_ISSUE((G) + HU_D - 2)                                                                                      \
+        const unsigned ra_ = lds_ring + (unsigned)((G) % HU_D) * HU_STAGE_BYTES + voff_lane;                          \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                              \
+            HU_DSREAD(AH[t], ra_, (t * 2 + 0) * 1024);                                                                \
+            HU_DSREAD(AL[t], ra_, (t * 2 + 1) * 1024);                                                                \
+        }                                                                                                             \
+    }
+// one product: NK k-steps starting at global stage G0, NT output tiles; BFRAG(s, bh, bl) yields the B operand of k-step s.  The fragments
+// of k-step s+1 are on their way from LDS while the 3*NT MFMAs of k-step s issue (two register sets; LDS returns data in order, so
+// "all but the newest 2*NT reads" = this k-step's have arrived).
+#define HU_GEMM(ACC, NT, NK, G0, BFRAG)                                                                               \
+    {                                                                                                                 \
+        half8 ah_[2][NT], al_[2][NT];                                                                                 \
+        HU_BEGIN((G0), NT, ah_[0], al_[0])                                                                            \
+        _Pragma("unroll") for (int s = 0; s < NK; ++s) {                                                              \
+            if (s + 1 < NK) { HU_BEGIN((G0) + s + 1, NT, ah_[(s + 1) & 1], al_[(s + 1) & 1]) }                        \
+            half8 bh_, bl_;                                                                                           \
+            BFRAG(s, bh_, bl_)                                                                                        \
+            HU_WAITL_N(s + 1 < NK ? 2 * NT : 0)                                                                       \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) { HU_MMA3(ACC[t], ah_[s & 1][t], al_[s & 1][t], bh_, bl_) } \
+        }                                                                                                             \
     }
 
 __global__ __launch_bounds__(64 * HU_WAVES) void k_hidden_update_s16(HuArgs a) {
@@ -585,9 +604,9 @@ __global__ __launch_bounds__(64 * HU_WAVES) void k_hidden_update_s16(HuArgs a) {
     const char* wbzr = reinterpret_cast<const char*>(a.Wzr);
     const char* wbq = reinterpret_cast<const char*>(a.Wq);
 
-    // ---- the weight pipeline starts before anything else: stages 0 .. HU_D-2 ------------------------------------------------
+    // ---- the weight pipeline starts before anything else: stages 0 .. HU_D-3 (HU_BEGIN(g) adds stage g + HU_D - 2) ---------------------
 #pragma unroll
-    for (int g = 0; g < HU_D - 1; ++g) HU_ISSUE(g)
+    for (int g = 0; g < HU_D - 2; ++g) HU_ISSUE(g)
 
     // biases (and the single-channel first layer) through LDS: per-lane global loads of them inside the activation code
     // serialised on ~90 separate memory round trips
