@@ -310,7 +310,7 @@ def spawn_ranks(a, argv):
     the GPU (a process that has initialised HIP must not exec or fork GPU workers on this pool)."""
     import socket
     import subprocess
-    if not a.dry_run:
+    if not a.dry_run and os.environ.get("TCS_MI355_DIST_BACKEND") != "gloo":      # (gloo rehearsal: ranks may share a GPU)
         have = count_gpus_sysfs()                    # no HIP / amdsmi call in the parent: it only starts the ranks
         if have is not None and have < a.gpus:
             raise SystemExit(f"bench.py --gpus {a.gpus}: this box exposes {have} GPU(s); one rank per GPU is the only supported layout")
