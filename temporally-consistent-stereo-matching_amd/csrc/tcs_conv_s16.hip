@@ -523,7 +523,12 @@ __global__ __launch_bounds__(64 * ROWS / RPW) void k_conv_s16(S16Args a) {
     static_assert(ROWS % RPW == 0 && (RPW == 1 || (!RS && EPI != TCS_EPI_DECONV2X && EPI != TCS_EPI_BLEND9)), "rows per wave");
     constexpr int NW = ROWS / RPW;                                  // waves per block
     constexpr int HALO = KS / 2, TAPS = KS * KS, TS = RS ? KS : TAPS;                       // TS: taps per stage
-    constexpr int IH = RS ? ROWS : STRIDE * ROWS + KS - STRIDE, IW = STRIDE * 32 + KS - STRIDE, IN_CH = IH * IW;
+    // A strided 1x1 convolution (the projection shortcut of a down-sampling residual block) reads every other pixel: the DMA gathers
+    // exactly those (per-lane source offsets are free), so the LDS tile is ROWS x 32 and dense.  Staging the full 2*ROWS-1 x 63
+    // window (3.4x the bytes, 56 KiB per stage: one workgroup per CU) made the 64 -> 96 shortcut at half resolution cost 136 us.
+    constexpr bool GATHER = KS == 1 && STRIDE == 2;
+    constexpr int LSTR = GATHER ? 1 : STRIDE;                                               // pixel stride inside the LDS tile
+    constexpr int IH = RS ? ROWS : (GATHER ? ROWS : STRIDE * ROWS + KS - STRIDE), IW = GATHER ? 32 : STRIDE * 32 + KS - STRIDE, IN_CH = IH * IW;
     constexpr int IN_UNITS = KSTEPS * 4 * IN_CH;                    // sub-tiles [kstep][lane half][hi|lo][IH][IW]
     constexpr int NPI = (IN_UNITS + 63) / 64, NPW = KSTEPS * TS * MT * 2, NP = NPI + NPW;
     constexpr int PPW = (NP + NW - 1) / NW;                         // DMA pieces per wave per stage
@@ -553,7 +558,8 @@ __global__ __launch_bounds__(64 * ROWS / RPW) void k_conv_s16(S16Args a) {
             const int sub = u / IN_CH, pos = u - sub * IN_CH;
             const int row = pos / IW, col = pos - row * IW;
             // padded coordinates; RS adds the filter row (0..KS-1) through the stage's base pointer
-            const int gy = min(STRIDE * y0 + row - HALO + 1, Hp - 1 - (RS ? KS - 1 : 0)), gx = min(STRIDE * x0 + col - HALO + 1, Wp - 1);
+            const int gy = GATHER ? min(STRIDE * (y0 + row) + 1, Hp - 1) : min(STRIDE * y0 + row - HALO + 1, Hp - 1 - (RS ? KS - 1 : 0));
+            const int gx = GATHER ? min(STRIDE * (x0 + col) + 1, Wp - 1) : min(STRIDE * x0 + col - HALO + 1, Wp - 1);
             voff[j] = ((unsigned)sub * plane + (unsigned)(gy * Wp + gx)) * 16u;
         } else {
             const int uw = (p - NPI) * 64 + lane;
@@ -598,7 +604,7 @@ __global__ __launch_bounds__(64 * ROWS / RPW) void k_conv_s16(S16Args a) {
         for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
 
     // operand fetch addresses inside a stage buffer
-    const unsigned addr_b0 = lds_base + (unsigned)((half * 2 * IN_CH + STRIDE * wave * RPW * IW + STRIDE * l31) * 16);
+    const unsigned addr_b0 = lds_base + (unsigned)((half * 2 * IN_CH + LSTR * wave * RPW * IW + LSTR * l31) * 16);
     const unsigned addr_a0 = lds_base + (unsigned)(W_OFF + lane * 16);
     struct Frag { half8 b_hi[RPW], b_lo[RPW], a_hi[MT], a_lo[MT]; };
 #define S16_DSREAD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "i"(OFF) : "memory")
@@ -606,8 +612,8 @@ __global__ __launch_bounds__(64 * ROWS / RPW) void k_conv_s16(S16Args a) {
     {                                                                                                                 \
         const int kk_ = (STEP) / TS, t_ = (STEP) % TS, dy_ = RS ? 0 : t_ / KS, dx_ = t_ % KS;  /* constants after unrolling */ \
         _Pragma("unroll") for (int j = 0; j < RPW; ++j) {                                                             \
-            S16_DSREAD(F.b_hi[j], addr_b, ((kk_ * 4 + 0) * IN_CH + (dy_ + STRIDE * j) * IW + dx_) * 16);              \
-            S16_DSREAD(F.b_lo[j], addr_b, ((kk_ * 4 + 1) * IN_CH + (dy_ + STRIDE * j) * IW + dx_) * 16);              \
+            S16_DSREAD(F.b_hi[j], addr_b, ((kk_ * 4 + 0) * IN_CH + (dy_ + LSTR * j) * IW + dx_) * 16);                \
+            S16_DSREAD(F.b_lo[j], addr_b, ((kk_ * 4 + 1) * IN_CH + (dy_ + LSTR * j) * IW + dx_) * 16);                \
         }                                                                                                             \
         _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                              \
             S16_DSREAD(F.a_hi[m], addr_a, (((kk_ * TS + t_) * MT + m) * 2 + 0) * 1024);                               \
@@ -752,7 +758,8 @@ __global__ __launch_bounds__(256) void k_s16_to_f32(const _Float16* __restrict__
 // ---------------------------------------------------------------------------------------------------------------------
 template <int KS, int MT, int ROWS, int KSTEPS, int NSTAGE, int STRIDE, int EPI, int RS = 0, int RPW = 1>
 static int launch_s16(S16Args& a, hipStream_t s) {
-    constexpr int IH = RS ? ROWS : STRIDE * ROWS + KS - STRIDE, IW = STRIDE * 32 + KS - STRIDE, TS = RS ? KS : KS * KS;
+    constexpr bool GATHER = KS == 1 && STRIDE == 2;                 // (as in the kernel)
+    constexpr int IH = RS ? ROWS : (GATHER ? ROWS : STRIDE * ROWS + KS - STRIDE), IW = GATHER ? 32 : STRIDE * 32 + KS - STRIDE, TS = RS ? KS : KS * KS;
     constexpr int NPI = (KSTEPS * 4 * IH * IW + 63) / 64, NP = NPI + KSTEPS * TS * MT * 2;
     constexpr size_t lds = (size_t)NSTAGE * NP * 1024;
     static_assert(lds <= 160 * 1024, "LDS budget");
@@ -841,6 +848,8 @@ static int s16_heuristic(const S16Args& a, int ksize, int stride, int kst1x1, in
         // fragment feeds two activation fragments): 31.4 -> 29.5 us (128 -> 128), 40.9 -> 38.1 us (192 -> 128) alone, -0.6 ms per frame
         // together; narrower or shallower layers lose with it (64 -> 64: 12.3 -> 15.2 us), gru08 does not move
         if (epilogue == TCS_EPI_LINEAR && a.nk >= 8 && a.nk <= 12 && a.nct32 >= 3 && a.nct32 <= 4) return 100000 + 20000 + 1000 + 800 + 10 + 2;
+        // ... and the feature extractor's big grids (two images at full / half resolution, 64 -> 64 and 96 -> 96): 251 -> 223 us, 108 -> 100 us
+        if (epilogue == TCS_EPI_LINEAR && blocks8 >= 1500 && a.nk >= 4 && a.nct32 >= 2 && a.nct32 <= 4) return 100000 + 20000 + 1000 + 800 + 10 + 2;
         return 100000 + 1000 + 400 + 10 + 1;
     }
     if (blocks8 >= 180) return 100000 + 1000 + 800 + 10 + 2;

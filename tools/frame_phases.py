@@ -28,3 +28,22 @@ for a, b in zip(ends[:-1], ends[1:]):
 print("frame_ms  head_ms  loop_ms  tail_ms  rgb_stem_start_after_prev_end_ms   (last %d plain frames of %d)" % (min(N, len(out)), len(out)))
 for o in out[-N:]:
     print("%8.2f %8.2f %8.2f %8.2f %8.2f" % o)
+# the head of the last plain frame, launch by launch (queue, start / end in us after the previous frame's end, duration, grid, kernel)
+import re
+plain = []
+for a, b in zip(ends[:-1], ends[1:]):
+    seg = rows_sorted = None
+    n_hu = sum(1 for e in ev[a + 1:b + 1] if "k_hidden_update" in e[2])
+    if n_hu == 32:
+        plain.append((a, b))
+if plain:
+    a, b = plain[-1]
+    t0 = ev[a][1]
+    print("\nhead of the last plain frame:")
+    for i in range(a + 1, b + 1):
+        r = rows[i]
+        if "k_hidden_update" in r["Kernel_Name"]:
+            break
+        st, en = (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3
+        n = re.sub(r"\(.*", "", re.sub(r"^void ", "", r["Kernel_Name"]))[:56]
+        print(f"q{r['Queue_Id']:>2s} {st:8.1f} {en:8.1f} {en - st:6.1f} g{int(r['Grid_Size_X']) // int(r['Workgroup_Size_X']):5d}x{r['Workgroup_Size_X']:>3s} {n}")
