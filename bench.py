@@ -82,16 +82,17 @@ class ClipRunner:
 
     def step(self):
         i1, i2, K, T = self.frames[self.t]
-        if self.prefetch:
-            # a video loop knows its next frame: its image-only stage (features, correlation pyramid, context) starts now, beside
-            # this frame's refinement loop (TCStereo.prefetch); the clip wraps, and a wrapped frame starts a new sequence
-            nxt = (self.t + 1) % self.n
-            self.model.prefetch(self.frames[nxt][0], self.frames[nxt][1], first=(nxt == 0))
         params = None
         if self.t > 0 and self.state is not None:
             flow_q, nets, fmap1, prev_T = self.state
             params = dict(K=K, T=T, previous_T=prev_T, last_disp=flow_q, last_net_list=nets, fmap1=fmap1, baseline=self.baseline)
         out = self.model(i1, i2, iters=self.iters, test_mode=True, params=params)
+        if self.prefetch:
+            # a video loop knows its next frame (resident here): its image-only stage (features, correlation pyramid, context) is launched
+            # right behind this frame and starts when this frame's refinement loop starts (TCStereo.prefetch); the clip wraps, and a
+            # wrapped frame starts a new sequence
+            nxt = (self.t + 1) % self.n
+            self.model.prefetch(self.frames[nxt][0], self.frames[nxt][1], first=(nxt == 0), inputs_ready=True)
         self.state = (out["flow_q"], out["net_list"], out["fmap1"], T)
         self.last = out
         self.t = (self.t + 1) % self.n

@@ -109,7 +109,7 @@ class TCStereo(nn.Module):
     def _pipeline(self):
         if getattr(self, "_graphs", None) is None:
             from tcs_mi355.graph import FrameGraphs
-            self._graphs = FrameGraphs(self._extract_stage, self._refine_stage, epoch_fn=self._weights_epoch,
+            self._graphs = FrameGraphs(self._extract_stage, self._refine_head, self._refine_loop, epoch_fn=self._weights_epoch,
                                        strict=os.environ.get("TCS_MI355_GRAPH_STRICT", "0") == "1")
         return self._graphs
 
@@ -119,16 +119,19 @@ class TCStereo(nn.Module):
         return bool(self.use_hip_graph)
 
     @torch.no_grad()
-    def prefetch(self, image1, image2, first=False):
+    def prefetch(self, image1, image2, first=False, inputs_ready=False):
         """Optional, for callers that know the next frame (a video loop): start the part of a frame that depends on nothing but its
-        two images — feature / context networks, correlation pyramid, context convolutions (tc_stereo.py:101-116,147-149) — NOW, on a
+        two images — feature / context networks, correlation pyramid, context convolutions (tc_stereo.py:101-116,147-149) — on a
         second stream, beside the refinement loop of the frame in flight.  The next `forward` with the SAME image tensors (same
-        storage, unmodified) picks the result up; any other call simply extracts again.  `first`: that frame will be called with
-        params=None (start of a sequence: the arg-max prior is then built with the correlation volume).  Call it before the
-        `forward` it is to overlap with.  Results are identical with and without it."""
+        objects, unmodified) picks the result up; any other call simply extracts again.  `first`: that frame will be called with
+        params=None (start of a sequence: the arg-max prior is then built with the correlation volume).
+        Call it right AFTER the `forward` it is to overlap with and pass `inputs_ready=True` when the images were complete on the
+        device before that `forward` was called (frames resident in memory): the extraction then starts when that frame's
+        refinement loop starts (its short state-dependent head runs undisturbed).  With `inputs_ready=False` it is ordered behind
+        everything queued on the current stream so far.  Results are identical with and without it."""
         if not image1.is_cuda:
             raise RuntimeError("TCStereo.prefetch needs HIP device tensors; there is no CPU fallback")
-        self._pipeline().prefetch(image1, image2, first=bool(first), use_graph=self._graph_mode())
+        self._pipeline().prefetch(image1, image2, first=bool(first), use_graph=self._graph_mode(), inputs_ready=bool(inputs_ready))
 
     @torch.no_grad()
     def forward(self, image1, image2, iters=12, params=None, test_mode=False, frame_id=0):
@@ -154,7 +157,8 @@ class TCStereo(nn.Module):
 
     def _frame(self, image1, image2, iters, temporal):
         """One frame as a pure launch sequence on the current stream (both stages back to back)."""
-        return self._refine_stage(self._extract_stage(image1, image2, temporal is None), iters, temporal)
+        feats = self._extract_stage(image1, image2, temporal is None)
+        return self._refine_loop(feats, self._refine_head(feats, temporal), iters)
 
     def _extract_stage(self, image1, image2, first):
         """Everything of a frame that depends only on its two images (tensors in, tensors out; capturable): matching features,
@@ -195,13 +199,12 @@ class TCStereo(nn.Module):
             inp_list, grad_list, net_list = context(cnet_list)
         return {"fmap1": fmap1, "corr_fn": corr_fn, "prior": prior, "inp_list": inp_list, "grad_list": grad_list, "net_list": net_list}
 
-    def _refine_stage(self, feats, iters, temporal):
-        """The state-dependent rest of a frame (tensors in, tensors out; capturable): prior from the arg-max or from the pose warp of
-        the previous frame, disparity completion, hidden-state warp, the refinement loop, upsampling (tc_stereo.py:119-229)."""
-        a = self.args
+    def _refine_head(self, feats, temporal):
+        """The state-dependent head of a frame (tensors in, tensors out; capturable): prior from the arg-max or from the pose warp of the
+        previous frame, disparity completion, hidden-state warp and fusion (tc_stereo.py:119-172) -> what the loop starts from."""
         first = temporal is None
         fmap1, corr_fn = feats["fmap1"], feats["corr_fn"]
-        inp_list, grad_list, net_list = feats["inp_list"], feats["grad_list"], feats["net_list"]
+        net_list = feats["net_list"]
         if first:
             last_net_list = None
             sparse_disp, cost, sparse_mask = feats["prior"] if feats["prior"] is not None else corr_fn.argmax_disp()
@@ -235,6 +238,16 @@ class TCStereo(nn.Module):
         if trace is not None:
             trace.update(sparse_disp=sparse_disp, cost=cost, sparse_mask=sparse_mask, disp_init=disp_init,
                          net0=[t.clone() for t in net_list], iters=[])
+        return {"coords1": coords1, "net_list": net_list}
+
+    def _refine_loop(self, feats, start, iters):
+        """The refinement loop and the upsampling (tc_stereo.py:175-229) from the head's disparity / hidden states (capturable)."""
+        a = self.args
+        fmap1, corr_fn = feats["fmap1"], feats["corr_fn"]
+        inp_list, grad_list = feats["inp_list"], feats["grad_list"]
+        coords1, net_list = start["coords1"], start["net_list"]
+        coords0 = self._coords0(fmap1)
+        trace = getattr(self, "_trace", None)
 
         # ---- refinement loop on pre-split activations (tcs_mi355/s16.py): hidden states, context features and the motion
         # feature buffer live in S16 pool buffers; 1-2 channel geometry (coords, disparity, gradients) stays fp32 ----

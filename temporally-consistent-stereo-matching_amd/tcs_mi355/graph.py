@@ -76,21 +76,26 @@ class _Slot:
 
 
 class _Entry:
-    def __init__(self, graph, static_in, static_out):
-        self.graph, self.static_in, self.static_out = graph, static_in, static_out
+    def __init__(self, graph, static_in, static_out, graph2=None):
+        self.graph, self.static_in, self.static_out, self.graph2 = graph, static_in, static_out, graph2
 
 
 class FrameGraphs:
-    """`extract_fn(image1, image2, first) -> feats`, `refine_fn(feats, iters, temporal) -> dict`.
+    """`extract_fn(image1, image2, first) -> feats`, `head_fn(feats, temporal) -> start`, `loop_fn(feats, start, iters) -> dict`.
+    REFINE is captured as two graphs, the short state-dependent head and the loop, with an event between their launches: a prefetch
+    made right after a frame's call waits for THAT event, so the next frame's EXTRACT runs beside this frame's loop and not beside
+    its head (a chain of small launches that the extractor's 2 400-workgroup launches would starve).
 
     `epoch_fn` returns a value that changes whenever a model parameter is replaced or written in place (`load_state_dict`, an
     optimiser step): a captured graph holds the packed weight images of the moment of capture, so every entry is dropped and
     re-captured when it changes.  `fell_back` counts the frames that ran eagerly because a capture failed; `strict=True` turns
     such a failure into an error instead (bench.py, tests).  `captures` counts captured REFINE keys."""
 
-    def __init__(self, extract_fn: Callable, refine_fn: Callable, warmup: int = 2, epoch_fn: Optional[Callable[[], object]] = None,
-                 strict: bool = False):
-        self.extract_fn, self.refine_fn, self.warmup, self.epoch_fn, self.strict = extract_fn, refine_fn, warmup, epoch_fn, strict
+    def __init__(self, extract_fn: Callable, head_fn: Callable, loop_fn: Callable, warmup: int = 2,
+                 epoch_fn: Optional[Callable[[], object]] = None, strict: bool = False):
+        self.extract_fn, self.head_fn, self.loop_fn = extract_fn, head_fn, loop_fn
+        self.warmup, self.epoch_fn, self.strict = warmup, epoch_fn, strict
+        self.loop_start = torch.cuda.Event()   # recorded on the caller's stream between a frame's head and its loop
         self.slots = [_Slot(), _Slot()]
         self.turn = 0                          # the slot the next EXTRACT goes to (unless it still holds unconsumed features)
         self.ex: Dict[tuple, Optional[List[_Entry]]] = {}
@@ -177,10 +182,10 @@ class FrameGraphs:
             torch.cuda.synchronize()
             return None
 
-    def _launch_extract(self, si: int, image1, image2, first: bool, use_graph: bool):
-        """EXTRACT into slot `si` on the extract stream: after everything queued on the caller's stream so far (the images are
-        ready; every earlier REFINE is ahead of us in that order, in particular the one that read this slot) and after the slot's
-        last reader."""
+    def _launch_extract(self, si: int, image1, image2, first: bool, use_graph: bool, inputs_ready: bool = False):
+        """EXTRACT into slot `si` on the extract stream: after the slot's last reader, and after everything queued on the caller's
+        stream so far (the images are ready) — or, with `inputs_ready` (the images were complete before the latest frame was
+        called), only after that frame's head: the extraction then overlaps its loop."""
         slot = self.slots[si]
         main = torch.cuda.current_stream()
         sx = self._stream(image1.device)
@@ -190,9 +195,12 @@ class FrameGraphs:
             if key not in self.ex:
                 self.ex[key] = self._capture_extract(key, image1, image2, first)
             entries = self.ex[key]
-        here = torch.cuda.Event()
-        here.record(main)
-        sx.wait_event(here)
+        if inputs_ready:
+            sx.wait_event(self.loop_start)
+        else:
+            here = torch.cuda.Event()
+            here.record(main)
+            sx.wait_event(here)
         sx.wait_event(slot.free)
         with torch.cuda.stream(sx):
             if entries is not None:
@@ -209,16 +217,17 @@ class FrameGraphs:
         slot.token, slot.ex_key, slot.fresh, slot.by_prefetch = self._token(image1, image2, first, use_graph), key, True, False
         self.turn = si ^ 1
 
-    def prefetch(self, image1, image2, first: bool = False, use_graph: bool = True) -> int:
-        """Launch the EXTRACT stage of a coming frame now (beside whatever the GPU is still doing); the next `__call__` with the same
-        image tensors (same storage, unmodified) uses it.  Call it BEFORE the `__call__` it is to overlap with.  Returns the slot."""
+    def prefetch(self, image1, image2, first: bool = False, use_graph: bool = True, inputs_ready: bool = False) -> int:
+        """Launch the EXTRACT stage of a coming frame; the next `__call__` with the same image tensor objects (unmodified) uses it.
+        Call it right after the `__call__` it is to overlap with, with `inputs_ready=True` when the images were on the device before
+        that call (see `_launch_extract`).  Returns the slot."""
         self._check_epoch()
         token = self._token(image1, image2, first, use_graph)
         for k in (0, 1):
             if self.slots[k].fresh and self._same(self.slots[k].token, token):
                 return k                                    # already there
         si = self._pick_slot()
-        self._launch_extract(si, image1, image2, first, use_graph)
+        self._launch_extract(si, image1, image2, first, use_graph, inputs_ready)
         self.slots[si].by_prefetch = True
         return si
 
@@ -237,7 +246,7 @@ class FrameGraphs:
             entries = []
             for si in (0, 1):
                 feats = self.ex[ex_key][si].static_out
-                run = lambda: self.refine_fn(feats, iters, _unflatten(static_in))
+                run = lambda: self.loop_fn(feats, self.head_fn(feats, _unflatten(static_in)), iters)
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
@@ -245,11 +254,15 @@ class FrameGraphs:
                         run()
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    out = run()
-                g.replay()
-                entries.append(_Entry(g, static_in, out))
+                g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1):
+                    start = self.head_fn(feats, _unflatten(static_in))
+                g1.replay()                               # (the loop graph is captured against the head graph's output tensors)
+                with torch.cuda.graph(g2):
+                    out = self.loop_fn(feats, start, iters)
+                g2.replay()
+                entries.append(_Entry(g1, static_in, out, graph2=g2))
+                entries[-1].start = start                 # (the loop graph holds raw pointers to the head graph's outputs)
             torch.cuda.synchronize()
             self.captures += 1
             for sl in self.slots:                       # the capture used both slots: whatever was prefetched into them is gone
@@ -289,12 +302,16 @@ class FrameGraphs:
             e = entries[si]
             for dst, src in zip(e.static_in, flat):
                 dst.copy_(src)
-            e.graph.replay()
+            e.graph.replay()                            # head
+            self.loop_start.record(main)
+            e.graph2.replay()                           # loop
             o = e.static_out
             out = {"flow": o["flow"].clone(), "flow_q": o["flow_q"].clone(), "net_list": [t.clone() for t in o["net_list"]],
                    "fmap1": o["fmap1"].clone()}
         else:
-            out = self.refine_fn(slot.feats, iters, temporal)
+            start = self.head_fn(slot.feats, temporal)
+            self.loop_start.record(main)
+            out = self.loop_fn(slot.feats, start, iters)
             out = dict(out, fmap1=out["fmap1"].clone())      # the slot's tensor is overwritten two frames from now
         slot.free.record(main)
         return out

@@ -558,12 +558,12 @@ def test_prefetch_overlaps_the_next_frames_extract_stage_without_changing_result
     def run(prefetch, wrong_first=False):
         outs, state = [], None
         for t, (i1, i2, K, T) in enumerate(frames):
-            if prefetch and t + 1 < len(frames):
-                nxt = frames[t + 1] if not (wrong_first and t == 0) else frames[-1]         # a prefetch that will not be used
-                model.prefetch(nxt[0], nxt[1], first=False)
             params = None if state is None else dict(K=K, T=T, previous_T=state[3], last_disp=state[0], last_net_list=state[1], fmap1=state[2],
                                                      baseline=baseline)
             o = model(i1, i2, iters=3, test_mode=True, params=params)
+            if prefetch and t + 1 < len(frames):
+                nxt = frames[t + 1] if not (wrong_first and t == 0) else frames[-1]         # a prefetch that will not be used
+                model.prefetch(nxt[0], nxt[1], first=False, inputs_ready=(t % 2 == 0))      # both orderings of the extract stream
             state = (o["flow_q"], o["net_list"], o["fmap1"], T)
             outs.append(o["flow"].clone())
         return outs
