@@ -3,7 +3,8 @@
 Same constructor (an argparse-style Namespace), same sub-module names (reference checkpoints load
 with strict=True), same `forward(image1, image2, iters, params, test_mode, frame_id)` signature and
 the same test-mode output dict, so evaluate_stereo.py's loop (evaluate_stereo.py:170-197) runs
-unchanged.  What differs is underneath: correlation build/lookup, the temporal warp, the GRU update
+unchanged.  One optional addition: `prefetch(next_image1, next_image2)` for video loops (the next frame's
+image-only stage overlaps the current frame's refinement loop).  What differs is underneath: correlation build/lookup, the temporal warp, the GRU update
 step, both U-Nets, every stencil and the feature extractor's convolutions are hand-written HIP kernels
 for gfx950 (libtcs_mi355.so); PyTorch-ROCm owns tensors, streams and graph capture.
 
@@ -25,8 +26,9 @@ from tcs_mi355 import ops, s16
 
 
 class autocast(contextlib.AbstractContextManager):
-    """evaluate_stereo.py imports `autocast` from here (evaluate_stereo.py:14).  The HIP path computes
-    in fp32 (MFMA fp32-in/fp32-acc), so this is a no-op context whatever `enabled` says."""
+    """evaluate_stereo.py imports `autocast` from here (evaluate_stereo.py:14).  The HIP path keeps fp32 tensors and fp32-grade
+    contractions (fp16 hi/lo split operands with fp32 accumulation, or fp32 MFMA — DESIGN.md section 5) whatever `enabled` says, so
+    this is a no-op context."""
 
     def __init__(self, enabled=False, **_):
         self.enabled = enabled
@@ -217,11 +219,17 @@ class TCStereo(nn.Module):
                 (-last_disp).float().contiguous(), last_fmap1.float().contiguous(), relative_T, K_scale,
                 K_scale_inv, baseline, cur_fmap=fmap1, want_fmap=False)
 
-        disp_init, _, _, net_list = self.disp_completor(sparse_disp, cost, sparse_mask, net_list, tanh_nets=True)
+        pool = self._s16pool
+        s16_head = "dc32" not in _X
+        if s16_head:
+            disp_init, _, _, net_list = self.disp_completor.run16(pool, sparse_disp, cost, sparse_mask, [c.float().contiguous() for c in net_list],
+                                                                  tanh_nets=True)
+        else:
+            disp_init, _, _, net_list = self.disp_completor(sparse_disp, cost, sparse_mask, net_list, tanh_nets=True)
         disp_init = disp_init.float().contiguous()
 
         if last_net_list is None:
-            warped = [torch.zeros_like(x) for x in net_list]
+            warped = None
         else:
             grid = ops.backward_grid(disp_init, back_T, K_scale, K_scale_inv, baseline)
             warped = []
@@ -230,14 +238,24 @@ class TCStereo(nn.Module):
                 if i + 1 < len(last_net_list):
                     grid = ops.grid_halve(grid)
 
-        net_list = self.fuse_previous_current_hidden_state(net_list, warped)       # (tanh applied by the completor's last convolutions)
+        # previous / current hidden-state fusion (tc_stereo.py:167-168; tanh applied by the completor's last convolutions)
+        if s16_head:
+            # the three Lightfuse cells on S16 tensors, updating the completor's hidden states in place; a first frame fuses with zeros
+            for i, (h, fuse) in enumerate(zip(net_list, self.previous_current_hideen_fuse)):
+                if warped is None:
+                    x = pool.get(("frame", "zero", i), h.B, h.C, h.H, h.W, h.device)          # never written: stays zero
+                else:
+                    x = s16.to_s16(warped[i], out=pool.get(("frame", "warped", i), h.B, h.C, h.H, h.W, h.device))
+                fuse.step16(pool, h, [x])
+        else:
+            net_list = self.fuse_previous_current_hidden_state(net_list, [torch.zeros_like(x) for x in net_list] if warped is None else warped)
 
         coords0 = self._coords0(fmap1)
         coords1 = (coords0 - disp_init).contiguous()
         trace = getattr(self, "_trace", None)          # debugging hook (eager mode only): intermediate tensors
         if trace is not None:
             trace.update(sparse_disp=sparse_disp, cost=cost, sparse_mask=sparse_mask, disp_init=disp_init,
-                         net0=[t.clone() for t in net_list], iters=[])
+                         net0=[t.float().clone() for t in net_list], iters=[])
         return {"coords1": coords1, "net_list": net_list}
 
     def _refine_loop(self, feats, start, iters):
@@ -253,7 +271,10 @@ class TCStereo(nn.Module):
         # feature buffer live in S16 pool buffers; 1-2 channel geometry (coords, disparity, gradients) stays fp32 ----
         pool = self._s16pool
         n3 = a.n_gru_layers == 3
-        nets = [s16.to_s16(t.float().contiguous(), out=pool.get(("frame", "net", i), t.shape[0], t.shape[1], t.shape[2], t.shape[3], t.device))
+        # (hidden states: the S16 tensors the head's completor / Lightfuse cells left, updated in place by the loop; fp32 only on the
+        # A/B path of the fp32-tensor head)
+        nets = [t if isinstance(t, s16.S16) else
+                s16.to_s16(t.float().contiguous(), out=pool.get(("frame", "net", i), t.shape[0], t.shape[1], t.shape[2], t.shape[3], t.device))
                 for i, t in enumerate(net_list)]
         grads16 = [s16.to_s16(t.float().contiguous(), out=pool.get(("frame", "ctxg", i), t.shape[0], t.shape[1], t.shape[2], t.shape[3], t.device))
                    for i, t in enumerate(grad_list)]

@@ -780,9 +780,41 @@ class DisparityCompletor(nn.Module):
                 self._cin(self.conv_out16_disp, [x16_out, ctx[2]], na)]
         return completed, disp_mono * 10, w, nets
 
+    def run16(self, pool, disp, cost, mask, ctx, tanh_nets=False):
+        """The block on pre-split (S16) tensors — the loop's kernels (tcs_conv2d_s16, S16 InstanceNorm, the up-blocks of the gradient
+        predictor) instead of the fp32-tensor ones: -> (completed fp32, 10 * disp_mono fp32, w fp32, three S16 hidden states).  `ctx`: the
+        three fp32 context tensors (update.py:369-399)."""
+        d = (disp / 10).float().contiguous()
+
+        def stem(seq, x):               # 1x1 (1 -> C) -> ReLU -> 1x1 (C -> C)
+            return conv16(pool, seq[2], [conv32to16(pool, seq[0], x.float().contiguous(), act="relu")])
+
+        def cin(seq, srcs, act="none"):  # conv -> InstanceNorm -> ReLU -> conv (update.py:325-367)
+            y = conv16(pool, seq[0], srcs)
+            return conv16(pool, seq[3], [s16.instance_norm(y, act="relu", out=y)], act=act)
+
+        c16 = [to16(pool, c, (id(self), "ctx", i)) for i, c in enumerate(ctx)]
+        x4_disp = conv16(pool, self.conv_disp_fuse[2], [conv16(pool, self.conv_disp_fuse[0], [stem(self.conv_disp_stem, d),
+                         stem(self.conv_cost_stem, cost), stem(self.conv_mask_stem, mask - 0.5)], act="relu")])
+        x4 = cin(self.conv_4_4, [x4_disp, c16[0]])
+        x8 = cin(self.conv_8_8, [cin(self.conv_4_8, [x4]), c16[1]])
+        x16_out = cin(self.conv_16_16, [cin(self.conv_8_16, [x8]), c16[2]])
+        x8_out = up_block16(pool, self.conv_16_8, x16_out, x8)
+        x4_out = up_block16(pool, self.conv_8_4, x8_out, x4)
+        disp_mono = conv16(pool, self.disp_head[2], [conv16(pool, self.disp_head[0], [x4_out], act="relu")], want32=True)
+        w = conv16(pool, self.w_head[2], [conv16(pool, self.w_head[0], [x4_out], act="relu")], act="sigmoid", want32=True)
+        completed = (w * d + (1 - w) * disp_mono) * 10
+        na = "tanh" if tanh_nets else "none"                # the caller's torch.tanh (tc_stereo.py:167) in the last convolutions' epilogues
+        nets = [cin(self.conv_out4_disp, [x4_out, c16[0]], na), cin(self.conv_out8_disp, [x8_out, c16[1]], na),
+                cin(self.conv_out16_disp, [x16_out, c16[2]], na)]
+        return completed, disp_mono * 10, w, nets
+
     def forward(self, disp, cost, mask, context_list, tanh_nets=False):
         """`tanh_nets` (not in the reference's signature): return tanh of the three new hidden states, which is what
         TCStereo.forward applies to them next (tc_stereo.py:167)."""
         if not disp.is_cuda:
             raise RuntimeError("DisparityCompletor: CPU tensor (the hot path has no CPU fallback)")
-        return self._forward_hip(disp, cost, mask, [c.float().contiguous() for c in context_list], tanh_nets)
+        if "dc32" in _X:                                    # A/B: round 2's fp32-tensor kernels
+            return self._forward_hip(disp, cost, mask, [c.float().contiguous() for c in context_list], tanh_nets)
+        completed, mono, w, nets = self.run16(pool_of(self), disp, cost, mask, [c.float().contiguous() for c in context_list], tanh_nets)
+        return completed, mono, w, [n.float() for n in nets]

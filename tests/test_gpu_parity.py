@@ -296,6 +296,12 @@ def test_cells_and_blocks_golden(dev, ops_golden, model):
         assert maxdiff(o, g[k]) <= 1e-4, k
     assert maxdiff(model.update_block.encoder(D(g["ub_flow"], dev), D(g["ub_corr"], dev)), g["enc_out"]) <= 1e-4
     assert maxdiff(model.previous_current_hideen_fuse[0](D(g["ub_h08"], dev), D(g["lf_x"], dev)), g["lf_out"]) <= 1e-5
+    # the same cell on pre-split tensors, as the frame's head runs it (in place on the hidden state)
+    from core.update import pool_of
+    from tcs_mi355 import s16
+    h16 = s16.to_s16(D(g["ub_h08"], dev))
+    model.previous_current_hideen_fuse[0].step16(pool_of(model), h16, [s16.to_s16(D(g["lf_x"], dev))])
+    assert maxdiff(h16.float(), g["lf_out"]) <= 1e-4
     assert maxdiff(model.hiddenstate_update(D(g["ub_h08"], dev), D(g["hu_delta"], dev)), g["hu_out"]) <= 1e-5
     grad, ctx = model.disp_grad_refine(D(g["prop_grad"], dev), D(g["prop_disp"], dev), [D(g[f"dg_ctx{i}"], dev) for i in range(3)])
     assert maxdiff(grad, g["dg_grad"]) <= 1e-4
