@@ -280,7 +280,8 @@ class _GateCell(nn.Module):
         big = h.H * h.W >= 10000 and self.convzr.kernel_size[0] == 3
         if ctot(cz) != ctot(cr):
             cz, cr = cz.contiguous(), cr.contiguous()
-        s16.gru_gates(packed16(self.convzr), [h, *xs], h, cz, cr, z_out=z, rh_out=rh, tile_cfg=121812 if (big and "rpwzr" in _X) else 0,
+        s16.gru_gates(packed16(self.convzr), [h, *xs], h, cz, cr, z_out=z, rh_out=rh,
+                      tile_cfg=121812 if (big and "rpwzr" in _X) else (101411 if (big and "zr1411" in _X) else 0),
                       addend_ctot=ctot(cz))
         return s16.gru_update(packed16(self.convq), [rh, *xs], h, z, cq, keep_z=self.keep_z, out=h,
                               tile_cfg=121812 if (big and "rpwq" in _X) else 0, addend_ctot=ctot(cq))

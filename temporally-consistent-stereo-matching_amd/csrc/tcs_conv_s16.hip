@@ -78,13 +78,15 @@ struct S16Args {
 // ---------------------------------------------------------------------------------------------------------------------
 // `st`: this lane's pixel is real (its stores happen).  False only in LINEAR launches with tap partials, where EVERY lane runs the
 // epilogue on a clamped (valid) pixel because the fold is an MFMA: the matrix instruction takes its weight rows from all 64 lanes.
-template <int EPI>
+// TP (LINEAR only): the launch writes tap partials.  A template parameter, not a run-time branch on a.tap_out: with the fold compiled into
+// every LINEAR kernel the register allocation of ALL of them was the fold's (220 VGPRs against 116: two waves per SIMD instead of four).
+template <int EPI, bool TP = false>
 __device__ __forceinline__ void s16_epilogue_tile(const S16Args& a, int b, int co0, int py, int px, const f32x16& acc, bool st = true) {
     const int H = a.H, W = a.W;
     const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
     const int Hp = H + 2, Wp = W + 2;
     // tap partials: this tile's four weight fragments (k-steps 2*tile, 2*tile + 1; hi, lo) are requested first, used last
-    const bool taps_here = EPI == TCS_EPI_LINEAR && a.tap_out != nullptr && (co0 >> 5) < a.tap_ntile;
+    const bool taps_here = TP && EPI == TCS_EPI_LINEAR && (co0 >> 5) < a.tap_ntile;
     uint4 tw0h = {0, 0, 0, 0}, tw0l = {0, 0, 0, 0}, tw1h = {0, 0, 0, 0}, tw1l = {0, 0, 0, 0};
     if (taps_here) {
         const uint4* twp = reinterpret_cast<const uint4*>(a.tap_w) + (size_t)(co0 >> 5) * 256 + (threadIdx.x & 63);
@@ -517,8 +519,22 @@ __device__ unsigned long long tcs_s16_stamps[4 * 8192];
 // one row per wave the 32-channel tile reads 4 operand fragments (1 KiB each) per 3 MFMAs: 4 SIMDs x 32 LDS clocks per 96 matrix clocks =
 // 133 % of the LDS port — the K loop is LDS-bandwidth bound (the measured 1.45 PFLOP/s ceiling).  Two rows per wave
 // read 6 fragments per 6 MFMAs (100 %), two rows x 64 channels 8 per 12 (67 %).  The block is ROWS / RPW waves; LDS per block is unchanged.
-template <int KS, int MT, int ROWS, int KSTEPS, int NSTAGE, int STRIDE, int EPI, int RS = 0, int RPW = 1>
-__global__ __launch_bounds__(64 * ROWS / RPW) void k_conv_s16(S16Args a) {
+// Occupancy target (second __launch_bounds__ argument of hipcc = minimum waves per SIMD): the register allocator lands 2-8 VGPRs above a
+// step of the occupancy table on the main instances (98-100 on the one-row LINEAR / GRU_ZR tiles: four waves per SIMD where 96 give
+// five; 136 / 132 on GRU_Q / tap partials: three where 128 give four).  On gru08.zr (1200 four-wave workgroups) five per CU instead of
+// four is the difference between one round of workgroups and two.
+constexpr int s16_min_waves(int MT, int EPI, int RPW, bool TP) {
+    // (two-row tiles: the K loop needs ~100 registers, prologue and epilogue take 182-212; forcing 128 makes the epilogue spill 54-108
+    // registers to scratch and costs 50 % of the kernel: 128 -> 128 43.5 against 29.3 us)
+    if (RPW != 1 || MT != 1) return 1;
+    if (TP || EPI == TCS_EPI_GRU_Q) return 4;
+    if (EPI == TCS_EPI_LINEAR || EPI == TCS_EPI_GRU_ZR) return 5;
+    return 1;
+}
+
+template <int KS, int MT, int ROWS, int KSTEPS, int NSTAGE, int STRIDE, int EPI, int RS = 0, int RPW = 1, bool TP = false>
+__global__ __launch_bounds__(64 * ROWS / RPW, s16_min_waves(MT, EPI, RPW, TP)) void k_conv_s16(S16Args a) {
+    static_assert(!TP || (EPI == TCS_EPI_LINEAR && KS == 3 && STRIDE == 1), "tap partials: 3x3 stride-1 LINEAR launches");
     static_assert(!RS || (KS == 3 && STRIDE == 1), "row split is for 3x3 stride-1 convolutions");
     static_assert(ROWS % RPW == 0 && (RPW == 1 || (!RS && EPI != TCS_EPI_DECONV2X && EPI != TCS_EPI_BLEND9)), "rows per wave");
     constexpr int NW = ROWS / RPW;                                  // waves per block
@@ -681,12 +697,12 @@ __global__ __launch_bounds__(64 * ROWS / RPW) void k_conv_s16(S16Args a) {
     const int px = x0 + l31, py = y0 + wave * RPW;
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
-        if (EPI == TCS_EPI_LINEAR && a.tap_out != nullptr) {
+        if (TP) {
             // tap partials: all 64 lanes run the epilogue (on clamped pixels; only real pixels store) — see s16_epilogue_tile
             const bool st = px < a.W && py + j < a.H;
 #pragma unroll
             for (int m = 0; m < MT; ++m)
-                s16_epilogue_tile<EPI>(a, b, (ct * MT + m) * 32 + 4 * half, min(py + j, a.H - 1), min(px, a.W - 1), acc[m * RPW + j], st);
+                s16_epilogue_tile<EPI, true>(a, b, (ct * MT + m) * 32 + 4 * half, min(py + j, a.H - 1), min(px, a.W - 1), acc[m * RPW + j], st);
         } else if (px < a.W && py + j < a.H) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) s16_epilogue_tile<EPI>(a, b, (ct * MT + m) * 32 + 4 * half, py + j, px, acc[m * RPW + j]);
@@ -756,14 +772,14 @@ __global__ __launch_bounds__(256) void k_s16_to_f32(const _Float16* __restrict__
 // ---------------------------------------------------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------------------------------------------------
-template <int KS, int MT, int ROWS, int KSTEPS, int NSTAGE, int STRIDE, int EPI, int RS = 0, int RPW = 1>
+template <int KS, int MT, int ROWS, int KSTEPS, int NSTAGE, int STRIDE, int EPI, int RS = 0, int RPW = 1, bool TP = false>
 static int launch_s16(S16Args& a, hipStream_t s) {
     constexpr bool GATHER = KS == 1 && STRIDE == 2;                 // (as in the kernel)
     constexpr int IH = RS ? ROWS : (GATHER ? ROWS : STRIDE * ROWS + KS - STRIDE), IW = GATHER ? 32 : STRIDE * 32 + KS - STRIDE, TS = RS ? KS : KS * KS;
     constexpr int NPI = (KSTEPS * 4 * IH * IW + 63) / 64, NP = NPI + KSTEPS * TS * MT * 2;
     constexpr size_t lds = (size_t)NSTAGE * NP * 1024;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    auto kern = k_conv_s16<KS, MT, ROWS, KSTEPS, NSTAGE, STRIDE, EPI, RS, RPW>;
+    auto kern = k_conv_s16<KS, MT, ROWS, KSTEPS, NSTAGE, STRIDE, EPI, RS, RPW, TP>;
     (void)hipGetLastError();                                        // a stale error of an earlier runtime call is not ours
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -788,6 +804,17 @@ static int launch_s16_cfg(S16Args& a, int cfg, hipStream_t s) {
     case (10000 + MT_ * 1000 + ROWS_ * 100 + KST_ * 10 + NST_): return launch_s16<KS, MT_, ROWS_, KST_, NST_, STRIDE, EPI, 1>(a, s);
 #define S16_CASE_RPW2(MT_, ROWS_, KST_, NST_) \
     case (20000 + MT_ * 1000 + ROWS_ * 100 + KST_ * 10 + NST_): return launch_s16<KS, MT_, ROWS_, KST_, NST_, STRIDE, EPI, 0, 2>(a, s);
+    if constexpr (KS == 3 && STRIDE == 1 && EPI == TCS_EPI_LINEAR) {
+        if (a.tap_out) {                                // tap partials: their own instances (see s16_epilogue_tile), the tiles the loop uses
+            switch (cfg) {
+                case 1411: return launch_s16<KS, 1, 4, 1, 1, STRIDE, EPI, 0, 1, true>(a, s);
+                case 1412: return launch_s16<KS, 1, 4, 1, 2, STRIDE, EPI, 0, 1, true>(a, s);
+                case 1812: return launch_s16<KS, 1, 8, 1, 2, STRIDE, EPI, 0, 1, true>(a, s);
+                case 21812: return launch_s16<KS, 1, 8, 1, 2, STRIDE, EPI, 0, 2, true>(a, s);
+                default: return TCS_EUNSUPPORTED;
+            }
+        }
+    } else if (a.tap_out) return TCS_EUNSUPPORTED;
     if constexpr (KS == 3 && STRIDE == 1 && (EPI == TCS_EPI_LINEAR || EPI == TCS_EPI_GRU_ZR || EPI == TCS_EPI_GRU_Q)) {
         switch (cfg) {
             S16_CASE_RPW2(1, 8, 1, 2) S16_CASE_RPW2(2, 8, 1, 2) S16_CASE_RPW2(1, 4, 1, 2) S16_CASE_RPW2(1, 4, 1, 1) S16_CASE_RPW2(2, 4, 1, 2)
@@ -844,12 +871,10 @@ static int s16_heuristic(const S16Args& a, int ksize, int stride, int kst1x1, in
         // patches with ONE 31 KiB stage, so that up to five workgroups per CU cover each other's fills (128->128: 25.4 -> 23.8 us,
         // 192->128: 33.4 -> 31.7 us, gru08.q 69.5 -> 58.7 us)
         if (a.nct32 >= 8 && a.nk >= 16) return 100000 + 1000 + 800 + 10 + 2;
-        // 128..192 -> 96..128 channels (context compress, fuse, w_head, encoder.conv): 8-row patches with TWO rows per wave (every weight
-        // fragment feeds two activation fragments): 31.4 -> 29.5 us (128 -> 128), 40.9 -> 38.1 us (192 -> 128) alone, -0.6 ms per frame
-        // together; narrower or shallower layers lose with it (64 -> 64: 12.3 -> 15.2 us), gru08 does not move
-        if (epilogue == TCS_EPI_LINEAR && a.nk >= 8 && a.nk <= 12 && a.nct32 >= 3 && a.nct32 <= 4) return 100000 + 20000 + 1000 + 800 + 10 + 2;
-        // ... and the feature extractor's big grids (two images at full / half resolution, 64 -> 64 and 96 -> 96): 251 -> 223 us, 108 -> 100 us
-        if (epilogue == TCS_EPI_LINEAR && blocks8 >= 1500 && a.nk >= 4 && a.nct32 >= 2 && a.nct32 <= 4) return 100000 + 20000 + 1000 + 800 + 10 + 2;
+        // (Two rows per wave — cfg 121812 — was the pick for 128..192 -> 96..128 channels and for the feature extractor's big grids while
+        // every LINEAR instance carried the tap-partial fold's 220 registers (two waves per SIMD).  With the fold in its own instances
+        // (95 registers, five waves) the one-row tile wins everywhere: 128 -> 128 25.9 against 29.8 us, 192 -> 128 33.8 / 38.7,
+        // half-resolution 96 -> 96 89.5 / 98.0, full-resolution 64 -> 64 201 / 215 — profiles/r03_conv_s16_occupancy_sweep.txt.)
         return 100000 + 1000 + 400 + 10 + 1;
     }
     if (blocks8 >= 180) return 100000 + 1000 + 800 + 10 + 2;
