@@ -291,6 +291,11 @@ class TCStereo(nn.Module):
         hu_delta = None              # the hidden-state update of iteration i-1 runs at the head of iteration i's coarse branch
         early32 = None               # gru32 of iteration i, launched during iteration i-1 (it needs only net16 / net32)
         plain = not a.slow_fast_gru and n3
+        # OFF by default (A/B token "g08split"): gru08's gate convolution split like gru16's — the net08 third of its input channels on a
+        # third parallel branch right after the hidden-state update, a K = 256 launch on the critical chain.  Measured on one box:
+        # 27.0 against 26.4 ms per frame (3 rounds each) — the early launch (128 -> 256 at 1/4 scale, 41 us alone) competes with the
+        # encoder and the coarse GRUs for the CUs, and a fifth stream shares one of the four hardware queues (profiles/r03_ab_logs.txt)
+        g08split = "g08split" in _X and trace is None and a.n_gru_layers >= 2
         for itr in range(iters):
             # Two independent chains open an iteration: [hidden-state update of the previous iteration -> gru32 -> gru16 ->
             # interp] needs only the hidden states; [corr lookup -> motion encoder] needs only coords1 / the flow written by the
@@ -303,6 +308,8 @@ class TCStereo(nn.Module):
             def coarse_branch():
                 if hu_delta is not None:
                     self.hiddenstate_update.run(pool, nets[0], hu_delta)
+                if g08split:
+                    hu_done.record(torch.cuda.current_stream())
                 if isinstance(up32_now, tuple):          # gru32 ran ahead together with the early share of gru16
                     return ub.gru16_late(pool, nets, up32_now[1])
                 if n3 and a.slow_fast_gru:
@@ -313,7 +320,15 @@ class TCStereo(nn.Module):
 
             up32_now = join(early32)                     # (None on the first iteration: gru32 then runs inside the coarse branch)
             early32 = None
-            (corr, m), up16 = fork_join([enc_branch, coarse_branch], site="iter")
+            def early08_branch():                        # third branch: gru08's gate convolution over net08, which is final after the
+                torch.cuda.current_stream().wait_event(hu_done)     # hidden-state update at the head of the coarse branch (enqueued first)
+                return ub.gru08_early(pool, nets, inp_list)
+
+            if g08split:
+                hu_done = torch.cuda.Event()
+                (corr, m), up16, zr_early = fork_join([enc_branch, coarse_branch, early08_branch], site="iter")
+            else:
+                ((corr, m), up16), zr_early = fork_join([enc_branch, coarse_branch], site="iter"), None
             if plain and trace is None and itr + 1 < iters:
                 # net16 is final for this iteration: gru32 of the NEXT iteration runs beside gru08 / flow head / refinement
                 def ahead():
@@ -322,7 +337,7 @@ class TCStereo(nn.Module):
                 early32 = spawn(ahead, site="gru32")
             sums = getattr(self, "_checksums", None)       # debugging hook (tools/determinism_check.py): device-side sums, no sync
             lazy = trace is None and sums is None           # the hooks want the flow head's / residual head's outputs as tensors
-            delta_flow = ub.run_fine(pool, nets, inp_list, m, up16, lazy=lazy)
+            delta_flow = ub.run_fine(pool, nets, inp_list, m, up16, lazy=lazy, zr_early=zr_early)
             # disp_q = x - (coords1 + delta), 5 * disp2disp_gradient_xy (update.py:199) and the gradient candidates in one
             # launch (with the flow head's last convolution finished from its tap partials); coords1 is replaced by the blend
             # kernel's output below

@@ -84,6 +84,17 @@ template <int EPI, bool TP = false>
 __device__ __forceinline__ void s16_epilogue_tile(const S16Args& a, int b, int co0, int py, int px, const f32x16& acc, bool st = true) {
     const int H = a.H, W = a.W;
     const size_t HW = (size_t)H * W, pix = (size_t)py * W + px;
+#ifdef TCS_S16_PROBE_SLIM
+    // diagnostic build (tools/conv_s16_probe.sh): a one-store epilogue, so that the register allocation — and with it the number of waves
+    // per SIMD — is the K loop's own.  Results are wrong by construction; only the timing of LINEAR launches means anything.
+    if (EPI == TCS_EPI_LINEAR && a.out32) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[r];
+        if (st) a.out32[((size_t)b * a.out_ctot + a.out_coff + min(co0, a.Cout - 1)) * HW + pix] = t;
+        return;
+    }
+#endif
     const int Hp = H + 2, Wp = W + 2;
     // tap partials: this tile's four weight fragments (k-steps 2*tile, 2*tile + 1; hi, lo) are requested first, used last
     const bool taps_here = TP && EPI == TCS_EPI_LINEAR && (co0 >> 5) < a.tap_ntile;
@@ -519,16 +530,20 @@ __device__ unsigned long long tcs_s16_stamps[4 * 8192];
 // one row per wave the 32-channel tile reads 4 operand fragments (1 KiB each) per 3 MFMAs: 4 SIMDs x 32 LDS clocks per 96 matrix clocks =
 // 133 % of the LDS port — the K loop is LDS-bandwidth bound (the measured 1.45 PFLOP/s ceiling).  Two rows per wave
 // read 6 fragments per 6 MFMAs (100 %), two rows x 64 channels 8 per 12 (67 %).  The block is ROWS / RPW waves; LDS per block is unchanged.
-// Occupancy target (second __launch_bounds__ argument of hipcc = minimum waves per SIMD): the register allocator lands 2-8 VGPRs above a
-// step of the occupancy table on the main instances (98-100 on the one-row LINEAR / GRU_ZR tiles: four waves per SIMD where 96 give
-// five; 136 / 132 on GRU_Q / tap partials: three where 128 give four).  On gru08.zr (1200 four-wave workgroups) five per CU instead of
-// four is the difference between one round of workgroups and two.
+// Occupancy target (second __launch_bounds__ argument of hipcc = minimum waves per SIMD).  The K loop of a one-row 32-channel tile needs
+// 59 VGPRs; what the kernel is allocated is its epilogue's appetite, and the allocator lands a few registers above a step of the
+// occupancy table on the main instances: 98 on LINEAR (four waves per SIMD where 96 give five), 136 / 132 on GRU_Q / tap partials
+// (three where 128 give four).  The targets below cost no spill.  GRU_ZR (100) is left alone: 96 costs two spilled registers and the
+// shipped gru08.zr tile (8 waves per workgroup, two workgroups per CU either way) gains nothing from a fifth wave.
 constexpr int s16_min_waves(int MT, int EPI, int RPW, bool TP) {
     // (two-row tiles: the K loop needs ~100 registers, prologue and epilogue take 182-212; forcing 128 makes the epilogue spill 54-108
     // registers to scratch and costs 50 % of the kernel: 128 -> 128 43.5 against 29.3 us)
+#ifdef TCS_S16_PROBE_SLIM
+    if (EPI == TCS_EPI_LINEAR && !TP) return RPW == 2 ? (MT == 2 ? 3 : 4) : (MT == 2 ? 4 : 8);
+#endif
     if (RPW != 1 || MT != 1) return 1;
     if (TP || EPI == TCS_EPI_GRU_Q) return 4;
-    if (EPI == TCS_EPI_LINEAR || EPI == TCS_EPI_GRU_ZR) return 5;
+    if (EPI == TCS_EPI_LINEAR) return 5;
     return 1;
 }
 
