@@ -526,10 +526,11 @@ __device__ unsigned long long tcs_s16_stamps[4 * 8192];
 #define S16_ABL_COMPUTE true
 #endif
 
-// RPW ("rows per wave") = 2: a wave owns TWO output rows, i.e. every weight fragment it fetches feeds two activation fragments.  With
-// one row per wave the 32-channel tile reads 4 operand fragments (1 KiB each) per 3 MFMAs: 4 SIMDs x 32 LDS clocks per 96 matrix clocks =
-// 133 % of the LDS port — the K loop is LDS-bandwidth bound (the measured 1.45 PFLOP/s ceiling).  Two rows per wave
-// read 6 fragments per 6 MFMAs (100 %), two rows x 64 channels 8 per 12 (67 %).  The block is ROWS / RPW waves; LDS per block is unchanged.
+// RPW ("rows per wave") = 2: a wave owns TWO output rows, i.e. every weight fragment it fetches feeds two activation fragments (6 operand
+// fragments per 6 MFMAs instead of 8).  The block is ROWS / RPW waves; LDS per block is unchanged.  A tile OPTION (cfg 12xxxx), not the
+// heuristic's choice: it only beat the one-row tile while that one was starved of occupancy (see s16_epilogue_tile's TP); with a
+// one-store epilogue (-DTCS_S16_PROBE_SLIM) every tile shape times within 5 % — DESIGN.md section 4.
+//
 // Occupancy target (second __launch_bounds__ argument of hipcc = minimum waves per SIMD).  The K loop of a one-row 32-channel tile needs
 // 59 VGPRs; what the kernel is allocated is its epilogue's appetite, and the allocator lands a few registers above a step of the
 // occupancy table on the main instances: 98 on LINEAR (four waves per SIMD where 96 give five), 136 / 132 on GRU_Q / tap partials
