@@ -19,6 +19,7 @@ lets the host enqueue frame t+1 while frame t runs.
 """
 from __future__ import annotations
 
+import gc
 import os
 import warnings
 from typing import Callable, Dict, List, Optional
@@ -60,6 +61,22 @@ def _tensors(obj, seen=None):
     elif hasattr(obj, "__dict__"):
         for o in vars(obj).values():
             yield from _tensors(o, seen)
+
+
+class _no_gc:
+    """No cyclic garbage collection while a stream is capturing.  torch.cuda.graph() collects before it starts capturing; a collection that
+    fires DURING the capture and finds an unreachable HIP graph / event of an earlier capture destroys it mid-capture, and the runtime aborts
+    the process (seen once: `Fatal Python error: Aborted ... Garbage-collecting` inside `_capture_extract` after a weight change had dropped
+    the previous captures)."""
+
+    def __enter__(self):
+        self.was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        if self.was:
+            gc.enable()
+        return False
 
 
 class _Slot:
@@ -120,6 +137,7 @@ class FrameGraphs:
                 self.rf.clear()
                 self.slots = [_Slot(), _Slot()]
                 self.turn, self.epoch = 0, now
+                gc.collect()                   # the dropped captures die here, not inside the next capture (see _no_gc)
 
     def _stream(self, device) -> torch.cuda.Stream:
         st = self._sx.get(device)
@@ -169,7 +187,7 @@ class FrameGraphs:
             entries = []
             for _ in range(2):                      # one executable (and one set of output tensors) per slot
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with _no_gc(), torch.cuda.graph(g):
                     feats = run()
                 g.replay()          # the first launch of an executable graph uploads it (~30 ms): pay that here, not in a timed frame
                 entries.append(_Entry(g, static_in, feats))
@@ -255,10 +273,10 @@ class FrameGraphs:
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
                 g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1):
+                with _no_gc(), torch.cuda.graph(g1):
                     start = self.head_fn(feats, _unflatten(static_in))
                 g1.replay()                               # (the loop graph is captured against the head graph's output tensors)
-                with torch.cuda.graph(g2):
+                with _no_gc(), torch.cuda.graph(g2):
                     out = self.loop_fn(feats, start, iters)
                 g2.replay()
                 entries.append(_Entry(g1, static_in, out, graph2=g2))

@@ -20,6 +20,7 @@ import torch
 
 ENABLED = os.environ.get("TCS_MI355_STREAMS", "1") == "1"
 SITES = os.environ.get("TCS_MI355_FORK_SITES", "all").split(",")       # diagnostic: restrict forking to named call sites
+OFF = set(t for t in os.environ.get("TCS_MI355_FORK_OFF", "").split(",") if t)      # diagnostic (A/B runs): call sites that run serially
 _POOL: dict = {}
 _DEPTH = 0          # nesting level of fork_join: each level owns its own side streams (a nested fork must never
                     # pick the stream it is already running on)
@@ -68,7 +69,7 @@ def spawn(fn: Callable[[], object], site: str = "", slot: int = 0) -> Spawned:
     current stream wait for it.  Used for work whose result is needed much later (the next iteration's gru32).  Spawns that
     are in flight at the same time take different `slot`s (one stream each)."""
     global _IN_SIDE, _DEPTH
-    if not ENABLED or _IN_SIDE > 0 or not torch.cuda.is_available() or ("all" not in SITES and site not in SITES):
+    if not ENABLED or _IN_SIDE > 0 or not torch.cuda.is_available() or ("all" not in SITES and site not in SITES) or site in OFF:
         return Spawned(fn(), None)
     cur = torch.cuda.current_stream()
     pool = _POOL.setdefault((cur.device, "spawn", cur.cuda_stream), [])
@@ -98,7 +99,7 @@ def fork_join(fns: Sequence[Callable[[], object]], site: str = "") -> list:
     """Run fns[0] on the current stream and fns[1:] on side streams; returns their results after joining.
     Every side chain starts after everything already enqueued on the current stream and the current stream waits for
     every side chain before continuing, so memory handed between the chains is ordered."""
-    if not ENABLED or len(fns) <= 1 or not torch.cuda.is_available() or ("all" not in SITES and site not in SITES):
+    if not ENABLED or len(fns) <= 1 or not torch.cuda.is_available() or ("all" not in SITES and site not in SITES) or site in OFF:
         return [f() for f in fns]
     global _DEPTH, _IN_SIDE
     if _IN_SIDE > 0:
