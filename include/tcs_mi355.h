@@ -368,12 +368,13 @@ typedef struct tcs_conv_s16_desc {
      * out16_split must be a multiple of 32; NULL = single output. */
     void* out16b;
     int out16b_groups, out16_split;
-    /* DECONV2X: InstanceNorm2d statistics of the output computed by the transposed convolution itself (the up-blocks are
-     * ConvTranspose2d -> InstanceNorm2d -> LeakyReLU, core/utils/basic_layers.py:28-35,57): every workgroup leaves (mean, M2)
-     * of its tile per channel, the last one to finish (a ticket counter; nobody waits) merges them into (mean, 1/sqrt(var + in_eps))
-     * per (b, channel), read by tcs_instance_norm_apply_s16.  in_stats: tcs_deconv_in_stats_bytes() bytes, ZERO-FILLED once by the
-     * caller before the first use (it holds the counters; every launch re-arms them); needs Cout/4 % 32 == 0 and B <= 16.  NULL = off. */
-    float* in_stats;
+    /* DECONV2X: InstanceNorm2d statistics of the output accumulated by the transposed convolution itself (the up-blocks are
+     * ConvTranspose2d -> InstanceNorm2d -> LeakyReLU, core/utils/basic_layers.py:28-35,57): every workgroup ADDS (sum x, sum x^2) of its
+     * tile, in 64-bit fixed point (2^20 / 2^16 units; integer atomics, so the result does not depend on the order of arrival), to
+     * in_stats[b][channel][2]; tcs_instance_norm_apply_s16 turns them into mean / rstd.  in_stats: tcs_deconv_in_stats_bytes() bytes
+     * (16 per (b, channel)), ZERO-FILLED by the caller before EVERY launch that accumulates into it; needs Cout/4 % 32 == 0 and an
+     * output grid of <= 2^20 pixels.  NULL = off.  in_eps: unused since ABI 6 (the apply call takes eps). */
+    void* in_stats;
     float in_eps;
     /* LINEAR, stride 1: "tap partials" of a FOLLOWING 3x3 convolution to tap_nout = 1 or 2 channels (FlowHead.conv2, core/update.py:13-17;
      * DispGradPredictor.residual_head[2], core/update.py:196,213), so that that convolution never runs as a launch: for each of the first
@@ -395,11 +396,12 @@ int tcs_resize_bilinear_s16(const void* x, int B, int groups, int H, int W, int 
 size_t tcs_instance_norm_s16_workspace_bytes(int B, int groups, int H, int W);
 int tcs_instance_norm_s16(const void* x, int B, int groups, int H, int W, float eps, int act, const void* addend, int addend_groups,
                           void* out, int out_groups, void* workspace, tcs_stream_t stream);
-/* The apply half of tcs_instance_norm_s16 for statistics already computed by the producing transposed convolution
- * (tcs_conv_s16_desc.in_stats; C = its Cout/4 channels, [H,W] = its OUTPUT grid): out = act((x - mean) * rstd) + addend. */
+/* The apply half of tcs_instance_norm_s16 for statistics accumulated by the producing transposed convolution
+ * (tcs_conv_s16_desc.in_stats; C = its Cout/4 channels, [H,W] = its OUTPUT grid): out = act((x - mean) / sqrt(var + eps)) + addend,
+ * biased variance as nn.InstanceNorm2d. */
 size_t tcs_deconv_in_stats_bytes(int B, int C, int H_in, int W_in);
 int tcs_instance_norm_apply_s16(const void* x, int B, int groups, int H, int W, int act, const void* addend, int addend_groups,
-                                void* out, int out_groups, const float* in_stats, int C, tcs_stream_t stream);
+                                void* out, int out_groups, const void* in_stats, int C, float eps, tcs_stream_t stream);
 /* Tap partials (tcs_conv_s16_desc.tap_*): weights [nout][C][3][3] * 2^scale_log2 -> fp16-split MFMA A fragments in the producer's
  * accumulator channel order, rows o*9 + t (tcs_tap_weights_floats floats; choose scale_log2 like tcs_pack_conv_weight_f16x3);
  * tcs_taps_sum: out[B,nout,H,W] = (addend + bias + sum over tiles and in-image taps) * scale (addend, bias nullable);

@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from core.corr import CorrBlock1D
 from core.extractor import BasicEncoder, MultiBasicEncoder, ResidualBlock, hip_head
-from core.update import (BasicMultiUpdateBlock, DispGradPredictor, DispRefine, DisparityCompletor, HiddenstateUpdater,
+from core.update import (IN_SUM_SLOTS, BasicMultiUpdateBlock, DispGradPredictor, DispRefine, DisparityCompletor, HiddenstateUpdater,
                          Lightfuse, _X, hip_conv)
 from core.utils.utils import coords_grid
 from tcs_mi355 import ops, s16
@@ -279,6 +279,7 @@ class TCStereo(nn.Module):
         grads16 = [s16.to_s16(t.float().contiguous(), out=pool.get(("frame", "ctxg", i), t.shape[0], t.shape[1], t.shape[2], t.shape[3], t.device))
                    for i, t in enumerate(grad_list)]
         dg_pre = self.disp_grad_refine.prepare(pool, grads16)      # the context share of three convolutions: once per frame
+        self.disp_grad_refine.begin_frame(pool, coords1.shape[0], coords1.device)
         refined = up_mask = None
         # coords1 - coords0, the motion encoder's flow input (tc_stereo.py:180): once here, afterwards the blend kernel writes
         # it for the next iteration — as a tensor for the 7x7 stem and into channel 127 of the motion feature buffer
@@ -345,7 +346,7 @@ class TCStereo(nn.Module):
                 disp_q, g5, cands = s16.flow_taps_step_grads(coords1, delta_flow, scale=5.0)
             else:
                 disp_q, g5, cands = ops.flow_step_grads(coords1, delta_flow, scale=5.0)
-            disp_grad, context = self.disp_grad_refine.run(pool, g5, cands, dg_pre, lazy=lazy)
+            disp_grad, context = self.disp_grad_refine.run(pool, g5, cands, dg_pre, lazy=lazy, slot=itr if itr < IN_SUM_SLOTS else None)
             last = itr == iters - 1
             refined, up_mask, fused = self.disp_refine.run(pool, disp_grad, disp_q, nets[0], context, want_mask=last, motion=motion)
             hu_delta = fused["delta_disp"]

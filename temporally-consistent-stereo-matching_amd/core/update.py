@@ -170,19 +170,20 @@ def to16(pool, x, key):
     return s16.to_s16(x.float().contiguous(), out=pool.get(key, B, C_, H, W, x.device))
 
 
-def up_block16(pool, block: Conv2x_IN, x: s16.S16, rem: s16.S16) -> s16.S16:
+IN_SUM_SLOTS = 64           # sets of InstanceNorm accumulators per fused up-block and frame (one per call; DispGradPredictor.begin_frame clears them)
+
+
+def up_block16(pool, block: Conv2x_IN, x: s16.S16, rem: s16.S16, slot=None) -> s16.S16:
     """Conv2x_IN(deconv=True, concat=False) on S16 tensors: transposed conv -> InstanceNorm -> LeakyReLU -> + rem ->
-    3x3 conv [-> InstanceNorm] -> LeakyReLU (basic_layers.py:38-77)."""
+    3x3 conv [-> InstanceNorm] -> LeakyReLU (basic_layers.py:38-77).  `slot` (0 .. IN_SUM_SLOTS-1): the transposed convolution accumulates
+    the InstanceNorm sums of its own output (tcs_conv_s16_desc.in_stats: fixed-point integer atomics) into set `slot` of the block's
+    accumulators and the statistics launch goes away; the CALLER clears the sets before they are used again (`up_block_sums(...).zero_()`
+    once per frame: the loop uses one set per iteration)."""
     dc = block.conv1.conv
     y = pool.get((id(dc), "o"), x.B, dc.out_channels, 2 * x.H, 2 * x.W, x.device)
     stats = None
-    if "infuse" in _X and s16.deconv_in_stats_ok(x.B, dc.out_channels, x.H, x.W):
-        # OFF by default (A/B token "infuse"): the transposed convolution reduces the InstanceNorm statistics of its own output
-        # (last-workgroup merge), which saves the statistics launch — and costs as much: device-coherent slot stores, their
-        # acknowledgement, a ticket atomic and the last workgroup's fetch are ~7 us of serial latency at the tail of a 15-us
-        # launch.  Measured three times on one box each: +1.3, +-0.3, +0.1..0.5 ms per frame (DESIGN.md section 4)
-        stats = pool.get32((id(dc), "in_stats"), (s16.nv.lib().tcs_deconv_in_stats_bytes(x.B, dc.out_channels, x.H, x.W) // 4,), x.device,
-                           zero=True)
+    if slot is not None and "noinfuse" not in _X and s16.deconv_in_stats_ok(x.B, dc.out_channels, x.H, x.W):
+        stats = up_block_sums(pool, block, x.B, x.device)[int(slot)]
     s16.deconv4x4s2(packed_deconv(dc), [x], out16=y, in_stats=stats)
     norm = (lambda **kw: s16.instance_norm_apply(y, stats, **kw)) if stats is not None else (lambda **kw: s16.instance_norm(y, **kw))
     if (y.H, y.W) != (rem.H, rem.W):         # odd-sized skip: nearest resize as the reference does (rare; through fp32)
@@ -195,6 +196,12 @@ def up_block16(pool, block: Conv2x_IN, x: s16.S16, rem: s16.S16) -> s16.S16:
         z = conv16(pool, block.conv2.conv, [y])
         return s16.instance_norm(z, act=act2, out=z)
     return conv16(pool, block.conv2.conv, [y], act=act2)
+
+
+def up_block_sums(pool, block: Conv2x_IN, B: int, device) -> torch.Tensor:
+    """int64 [IN_SUM_SLOTS, B, C, 2]: the fixed-point InstanceNorm accumulators of `up_block16(..., slot=)` for this block."""
+    dc = block.conv1.conv
+    return pool.get_i64((id(dc), "in_sums"), (IN_SUM_SLOTS, int(B), dc.out_channels, 2), device)
 
 
 def hip_conv(conv, srcs, act="none", **kw):
@@ -637,10 +644,17 @@ class DispGradPredictor(nn.Module):
             pre.append(out)
         return pre
 
-    def run(self, pool, g5: torch.Tensor, cands: torch.Tensor, pre, lazy: bool = False):
+    def begin_frame(self, pool, B: int, device):
+        """Once per frame, before the loop: clears the InstanceNorm accumulators of the two up-blocks (`run(..., slot=itr)` uses one set
+        per iteration; two memsets per frame instead of two statistics launches per iteration)."""
+        for blk in (self.conv_16_8, self.conv_8_4):
+            up_block_sums(pool, blk, B, device).zero_()
+
+    def run(self, pool, g5: torch.Tensor, cands: torch.Tensor, pre, lazy: bool = False, slot=None):
         """g5 = 5 * gradient [N,2,H,W] fp32, cands [N,32,H,W] fp32, pre: `prepare(pool, clist)` of the 3 S16 context tensors
         (64 ch at 1/4, 1/8, 1/16) -> (gradient fp32 [N,2,H,W], context S16 [N,64,H,W]).  `lazy`: the gradient as
-        (s16.Taps of residual_head[2], g5, 0.2) for DispRefine.run, which finishes (5*grad + residual) / 5 in its candidate stencil."""
+        (s16.Taps of residual_head[2], g5, 0.2) for DispRefine.run, which finishes (5*grad + residual) / 5 in its candidate stencil.
+        `slot`: see up_block16 (the frame loop passes its iteration index after `begin_frame`)."""
         def feat(conv, srcs, share):
             n = sum(t.C for t in srcs)
             return conv16(pool, conv, srcs, act="relu", addend=share, pc=packed16_part(conv, ((0, n),), with_bias=False))
@@ -670,8 +684,8 @@ class DispGradPredictor(nn.Module):
         x8 = feat(self.conv_8_8[0], [x8], pre[1])
         x16 = conv16(pool, self.conv_8_16[0], [x8], act="relu")                  # 3x3 stride 2
         x16 = feat(self.conv_16_16[0], [x16], pre[2])
-        x8_up = up_block16(pool, self.conv_16_8, x16, x8)
-        x4_up = up_block16(pool, self.conv_8_4, x8_up, x4)
+        x8_up = up_block16(pool, self.conv_16_8, x16, x8, slot=slot)
+        x4_up = up_block16(pool, self.conv_8_4, x8_up, x4, slot=slot)
 
         rh0, co0 = self.residual_head[0], self.conv_out[0]
         if "noheadfuse" not in _X and rh0.out_channels % 32 == 0:

@@ -63,8 +63,7 @@ struct S16Args {
     const float* bl_cand; int bl_cand_ctot; const float* bl_disp;
     float* bl_refined; float* bl_delta; float* bl_coords1; float* bl_flow; _Float16* bl_f16; int bl_f16_groups, bl_f16_ch;
     _Float16* out16b; int out16b_groups, out16_split;   // LINEAR: channels >= out16_split go to this second S16 tensor (tcs_mi355.h)
-    float* in_ws;                       // DECONV2X: InstanceNorm statistics of the output, see s16_deconv_stats() (nullable)
-    float in_eps;
+    void* in_ws;                        // DECONV2X: fixed-point (sum, sum of squares) accumulators of the output, see s16_deconv_sums() (nullable)
     const float* tap_w; float* tap_out; int tap_nout, tap_ntile;   // LINEAR: tap partials of a following 3x3 conv to 1-2 channels (tcs_stencil.hip)
     float tap_unscale;
     int ablate;                         // diagnostic builds only (-DTCS_S16_ABLATE, tools/conv_s16_ablate.py): bit 0 skip the
@@ -301,45 +300,32 @@ __device__ __forceinline__ void s16_epilogue_tile(const S16Args& a, int b, int c
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// InstanceNorm statistics of a transposed convolution's output, computed by the convolution itself (TCS_EPI_DECONV2X with
+// InstanceNorm statistics of a transposed convolution's output, accumulated by the convolution itself (TCS_EPI_DECONV2X with
 // tcs_conv_s16_desc.in_stats): the up-blocks of both U-Nets are ConvTranspose2d -> InstanceNorm2d -> LeakyReLU
 // (core/utils/basic_layers.py:28-35,57), and the statistics pass was a launch of its own on the iteration's serial chain.
-//   * every workgroup reduces its tile — ROWS x 32 pixels of the input grid x 32 output channels of ONE output parity, i.e.
-//     ROWS x 32 values of each of 32 real channels — to (mean, M2) per channel: two-pass inside a wave (sum -> mean -> squared
-//     deviations, as the reference's variance), Chan's pairwise merge across the waves, and writes them to its slot;
-//   * a ticket counter per batch element tells the LAST workgroup to finish; that one merges all slots (fixed order, so the
-//     result does not depend on who was last) into (mean, 1/sqrt(var + eps)) per channel and re-arms the counter.
-// No workgroup ever waits for another one.  The values are the STORED ones (hi + lo of the S16 split), which is what the
-// apply kernel normalises.  Workspace (floats): [0, 16): ticket counters (uint, one per batch element, B <= 16; zero before the
-// first launch), then finals [B][C][2], then slots [B][nct32][npatch][32][2].
+// Every workgroup reduces its tile — ROWS x 32 pixels of the input grid x 32 output channels of ONE output parity — to
+// (sum x, sum x^2) per channel in a fixed order (butterfly inside a wave, waves in row order), converts them to FIXED POINT
+// (2^20 and 2^16 units) and adds them to the 64-bit accumulators [B][C][2] with fire-and-forget atomics: integer addition
+// commutes, so the result does not depend on the order the workgroups arrive in (bit-reproducible), nobody waits and nobody
+// is last.  The values are the STORED ones (hi + lo of the S16 split), which is what the apply kernel normalises.  The
+// caller zero-fills the accumulators before the launch (core/update.py keeps one set per iteration and clears them all with
+// one memset per frame).  (Three earlier versions kept (mean, M2) slots per workgroup and had the last workgroup — a ticket
+// counter — merge them: device-coherent stores, their acknowledgement, the ticket and the merge were ~7 us of serial
+// latency at the tail of a 15-us launch, as much as the statistics launch they replaced)
+// Resolution: |x| <= 65504 and <= 2^20 pixels per channel keep both sums inside 63 bits; a partial sum is rounded to 1e-6
+// (1.5e-5 for the squares), i.e. <= 3e-8 / 4e-7 per pixel of a 120 x 160 grid — below the fp32 rounding of the sums themselves.
 // ---------------------------------------------------------------------------------------------------------------------
-#define S16_IN_WS_HEAD 16
-#define S16_IN_MAXLD 12             // 16-byte loads per thread of the last workgroup's slot fetch
-// do the slots of one batch element (+ the merge scratch) fit the last workgroup's fetch and the kernel's LDS?
-static inline bool s16_in_stats_fits(int nct32, int npatch, int C, int threads, size_t lds_bytes) {
-    const size_t nfl = (size_t)nct32 * npatch * 64;
-    return nfl <= (size_t)threads * 4 * S16_IN_MAXLD && (8 + nfl + 12 * (size_t)C) * sizeof(float) <= lds_bytes;
-}
-// ... for a 3x3 stride-1 tile configuration MT*1000 + ROWS*100 + KSTEPS*10 + NSTAGE on an [H, W] input grid with 4*C output channels
-static inline bool s16_cfg_in_stats_ok(int cfg, int C, int H, int W) {
-    const int mt = (cfg / 1000) % 10, rows = (cfg / 100) % 10, kst = (cfg / 10) % 10, nst = cfg % 10;
-    if (mt < 1 || rows < 1 || kst != 1 || nst < 1) return false;
-    const int np = ((rows + 2) * 34 * 4 + 63) / 64 + 9 * mt * 2;                     // 1 KiB DMA pieces per stage (k_conv_s16: NP)
-    const int npatch = ((W + 31) / 32) * ((H + rows - 1) / rows);
-    return s16_in_stats_fits(4 * C / 32, npatch, C, 64 * rows, (size_t)nst * np * 1024);
-}
+#define S16_IN_SCALE_SUM 1048576.f
+#define S16_IN_SCALE_SQ 65536.f
 template <int MT, int ROWS>
-__device__ __forceinline__ void s16_deconv_stats(const S16Args& a, int b, int ct, int patch, int py, int px, int wave, int lane,
-                                                 const f32x16* acc, float* lds /* >= max(ROWS * 64, 8 + 12 * C) floats, free to use */) {
+__device__ __forceinline__ void s16_deconv_sums(const S16Args& a, int b, int ct, int py, int px, int wave, int lane,
+                                                const f32x16* acc, float* lds /* >= ROWS * 64 floats, free to use */) {
     const int C = a.hidden, l31 = lane & 31, half = lane >> 5;
     const bool valid = px < a.W && py < a.H;
-    const int ncol = min(32, a.W - (px - l31)), n_wave = py < a.H ? ncol : 0;       // wave-uniform: this row's valid pixels
-    const int nslot_b = a.nct32 * a.npatch;
-    float* finals = a.in_ws + S16_IN_WS_HEAD + (size_t)b * C * 2;
-    float* slots = a.in_ws + S16_IN_WS_HEAD + (size_t)a.B * C * 2 + (size_t)b * nslot_b * 64;
+    unsigned long long* sums = reinterpret_cast<unsigned long long*>(a.in_ws) + (size_t)b * C * 2;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        float v[16], mean[16], m2[16];
+        float s1[16], s2[16];
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             half2_t hi, lo;
@@ -350,125 +336,45 @@ __device__ __forceinline__ void s16_deconv_stats(const S16Args& a, int b, int ct
             hi = __builtin_convertvector(x, half2_t);
             const float2_t back = __builtin_convertvector(hi, float2_t);
             lo = __builtin_convertvector(x - back, half2_t);
-            v[r] = valid ? (float)hi[0] + (float)lo[0] : 0.f;
-            v[r + 1] = valid ? (float)hi[1] + (float)lo[1] : 0.f;
+            const float v0 = valid ? (float)hi[0] + (float)lo[0] : 0.f, v1 = valid ? (float)hi[1] + (float)lo[1] : 0.f;
+            s1[r] = v0; s1[r + 1] = v1;
+            s2[r] = v0 * v0; s2[r + 1] = v1 * v1;
         }
-        const float inv_n = n_wave > 0 ? 1.0f / (float)n_wave : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float sum = v[r];
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);          // over the 32 pixels of this lane half
-            mean[r] = sum * inv_n;
-            const float d = valid ? v[r] - mean[r] : 0.f;
-            float q = d * d;
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-            m2[r] = q;
+            for (int o = 16; o > 0; o >>= 1) {             // over the 32 pixels of this lane half
+                s1[r] += __shfl_xor(s1[r], o, 64);
+                s2[r] += __shfl_xor(s2[r], o, 64);
+            }
         }
         // wave partials -> LDS [wave][half][16 regs][2]; lanes 0 and 32 hold their half's 16 channels
         __syncthreads();                                   // the stage buffers are free once every wave has left the K loop
         if (l31 == 0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                lds[((wave * 2 + half) * 16 + r) * 2 + 0] = mean[r];
-                lds[((wave * 2 + half) * 16 + r) * 2 + 1] = m2[r];
+                lds[((wave * 2 + half) * 16 + r) * 2 + 0] = s1[r];
+                lds[((wave * 2 + half) * 16 + r) * 2 + 1] = s2[r];
             }
         }
         __syncthreads();
-        if (wave == 0 && lane < 32) {                      // lane = (half, r): merge the ROWS waves in row order (Chan et al.)
-            const int y0 = py;                             // wave 0's row = the patch's first row
-            float n = 0.f, mu = 0.f, q = 0.f;
+        if (wave == 0 && lane < 32) {                      // lane = (half, r): the ROWS waves in row order
+            float t1 = 0.f, t2 = 0.f;
 #pragma unroll
             for (int w = 0; w < ROWS; ++w) {
-                const float ni = (y0 + w < a.H) ? (float)ncol : 0.f;
-                if (ni > 0.f) {
-                    const float mi = lds[((w * 2 + (lane >> 4)) * 16 + (lane & 15)) * 2], qi = lds[((w * 2 + (lane >> 4)) * 16 + (lane & 15)) * 2 + 1];
-                    const float tot = n + ni, f = ni / tot, dlt = mi - mu;
-                    mu += dlt * f;
-                    q += qi + dlt * dlt * n * f;
-                    n = tot;
-                }
+                t1 += lds[((w * 2 + (lane >> 4)) * 16 + (lane & 15)) * 2];
+                t2 += lds[((w * 2 + (lane >> 4)) * 16 + (lane & 15)) * 2 + 1];
             }
-            // channel of (half, r) inside the tile: 4*half + (r&3) + 8*(r>>2)
-            const int hh = lane >> 4, r = lane & 15, cin_tile = 4 * hh + (r & 3) + 8 * (r >> 2);
-            // device-coherent (write-through) stores: the slots cross XCDs without an L2 write-back.  (A __threadfence() per workgroup —
-            // an L2 write-back of everything dirty, i.e. of the output tensor being written — cost ~20 us per launch.)
-            float* sl = slots + ((size_t)(ct * MT + m) * a.npatch + patch) * 64;
-            __hip_atomic_store(sl + cin_tile * 2 + 0, mu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(sl + cin_tile * 2 + 1, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // channel of (half, r) inside the tile: 4*half + (r&3) + 8*(r>>2); the tile's 32 output channels of the 4*C lie in one parity
+            const int hh = lane >> 4, r = lane & 15, cout = (ct * MT + m) * 32 + 4 * hh + (r & 3) + 8 * (r >> 2);
+            if (cout < a.Cout) {
+                const int c = cout % C;
+                const long long q1 = __float2ll_rn(t1 * S16_IN_SCALE_SUM), q2 = __float2ll_rn(t2 * S16_IN_SCALE_SQ);
+                __hip_atomic_fetch_add(sums + c * 2 + 0, (unsigned long long)q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(sums + c * 2 + 1, (unsigned long long)q2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
-    // ---- ticket: the last workgroup of this batch element merges every slot ------------------------------------------------
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the slot stores above are acknowledged at device scope ...
-    __syncthreads();                                       // ... for every wave of this workgroup, before its ticket is drawn
-    unsigned* counter = reinterpret_cast<unsigned*>(a.in_ws) + b;
-    if (threadIdx.x == 0) {
-        const unsigned total = (unsigned)(a.npatch * a.nct);
-        const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        reinterpret_cast<unsigned*>(lds)[0] = (old == total - 1) ? 1u : 0u;
-    }
-    __syncthreads();
-    if (reinterpret_cast<unsigned*>(lds)[0] == 0u) return;
-    const int tiles_per_par = C / 32;                      // C % 32 == 0 is checked by the launcher when statistics are requested
-    // All slots of this batch element come into LDS with one batch of device-coherent (sc1: not served from this XCD's L2) 16-byte
-    // loads, every load in flight at once — the slots live at the memory side, ~1.5 us away, and a first version that walked them with
-    // a load -> merge loop per thread paid that latency 24 times (+12 us per launch).  The launcher guarantees that they fit
-    // (s16_in_stats_fits).  Then one thread per (parity, channel) merges its npatch slots in patch order, and the four parities of a
-    // channel are merged in parity order: a fixed order, whoever came last.
-    constexpr int NTH = 64 * ROWS;
-    const int nfl = nslot_b * 64;
-    float* cp = lds + 8;
-    float* mo = cp + nfl;
-    {
-        float4_t r[S16_IN_MAXLD];
-#pragma unroll
-        for (int k = 0; k < S16_IN_MAXLD; ++k) {
-            const float* src = slots + min((int)(threadIdx.x + k * NTH) * 4, nfl - 4);
-            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r[k]) : "v"(src) : "memory");
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int k = 0; k < S16_IN_MAXLD; ++k) {
-            const int i = (int)(threadIdx.x + k * NTH) * 4;
-            if (i < nfl) *reinterpret_cast<float4_t*>(cp + i) = r[k];
-        }
-    }
-    __syncthreads();
-    for (int item = threadIdx.x; item < 4 * C; item += NTH) {
-        const int par = item / C, c = item - par * C;
-        const float* sl = cp + (size_t)(par * tiles_per_par + (c >> 5)) * a.npatch * 64 + (c & 31) * 2;
-        float n = 0.f, mu = 0.f, q = 0.f;
-        int yy = 0, xx = 0;
-        for (int p = 0; p < a.npatch; ++p) {
-            const float s_mu = sl[p * 64], s_q = sl[p * 64 + 1];
-            const float ni = (float)(min(ROWS, a.H - yy) * min(32, a.W - xx));
-            const float tot = n + ni, f = ni / tot, dlt = s_mu - mu;
-            mu += dlt * f;
-            q += s_q + dlt * dlt * n * f;
-            n = tot;
-            xx += 32;
-            if (xx >= a.W) { xx = 0; yy += ROWS; }
-        }
-        mo[item * 3 + 0] = n;
-        mo[item * 3 + 1] = mu;
-        mo[item * 3 + 2] = q;
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += NTH) {
-        float n = 0.f, mu = 0.f, q = 0.f;
-#pragma unroll
-        for (int par = 0; par < 4; ++par) {
-            const float ni = mo[(par * C + c) * 3], mi = mo[(par * C + c) * 3 + 1], qi = mo[(par * C + c) * 3 + 2];
-            const float tot = n + ni, f = ni / tot, dlt = mi - mu;
-            mu += dlt * f;
-            q += qi + dlt * dlt * n * f;
-            n = tot;
-        }
-        finals[c * 2 + 0] = mu;
-        finals[c * 2 + 1] = 1.0f / sqrtf(q / n + a.in_eps);
-    }
-    if (threadIdx.x == 0) *counter = 0u;                   // re-armed for the next launch (stream order: nobody else is running)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -711,6 +617,14 @@ __global__ __launch_bounds__(64 * ROWS / RPW, s16_min_waves(MT, EPI, RPW, TP)) v
     S16_STAMP(2)
 
     const int px = x0 + l31, py = y0 + wave * RPW;
+    if constexpr (EPI == TCS_EPI_DECONV2X) {
+        // InstanceNorm sums FIRST: their atomics travel to the memory side (~2 us) while the tile is stored below.  (After the stores the
+        // same code made the launch 6-9 us longer — as much as the statistics launch it replaces.)
+        if (a.in_ws) {
+            extern __shared__ __attribute__((aligned(16))) float s16_dyn_lds[];
+            s16_deconv_sums<MT, ROWS>(a, b, ct, py, px, wave, lane, acc, s16_dyn_lds);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
         if (TP) {
@@ -722,12 +636,6 @@ __global__ __launch_bounds__(64 * ROWS / RPW, s16_min_waves(MT, EPI, RPW, TP)) v
         } else if (px < a.W && py + j < a.H) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) s16_epilogue_tile<EPI>(a, b, (ct * MT + m) * 32 + 4 * half, py + j, px, acc[m * RPW + j]);
-        }
-    }
-    if constexpr (EPI == TCS_EPI_DECONV2X) {
-        if (a.in_ws) {
-            extern __shared__ __attribute__((aligned(16))) float s16_dyn_lds[];
-            s16_deconv_stats<MT, ROWS>(a, b, ct, patch, py, px, wave, lane, acc, s16_dyn_lds);
         }
     }
 #ifdef TCS_S16_ABLATE
@@ -804,7 +712,6 @@ static int launch_s16(S16Args& a, hipStream_t s) {
     a.npx = tcs_cdiv(a.W, 32);
     a.nct = a.nct32 / MT;
     a.npatch = a.npx * tcs_cdiv(a.H, ROWS);
-    if (a.in_ws && !s16_in_stats_fits(a.nct32, a.npatch, a.hidden, 64 * ROWS / RPW, lds)) return TCS_EUNSUPPORTED;   // (checked before, s16_cfg_in_stats_ok)
     if (a.csplit > 0 && a.nct % a.csplit != 0) a.csplit = 1;
     hipLaunchKernelGGL(kern, dim3(a.npatch * a.nct, a.B), dim3(64 * ROWS / RPW), lds, s, a);
     return tcs_launch_status();
@@ -900,13 +807,8 @@ static int s16_heuristic(const S16Args& a, int ksize, int stride, int kst1x1, in
 extern "C" {
 
 size_t tcs_deconv_in_stats_bytes(int B, int C, int H, int W) {
-    if (B <= 0 || B > S16_IN_WS_HEAD || C <= 0 || C % 32 != 0 || H <= 0 || W <= 0) return 0;
-    // the smallest patch any tile configuration uses is 4 rows x 32 columns of the INPUT grid
-    const size_t npatch = (size_t)tcs_cdiv(W, 32) * tcs_cdiv(H, 4), nct32 = (size_t)4 * C / 32;
-    // 0 = not supported at this size (the last workgroup's fetch is sized for the loop's up-blocks): neither the 4-row nor the 8-row
-    // two-stage tile can hold the slots; callers then use the two-launch tcs_instance_norm_s16
-    if (!s16_cfg_in_stats_ok(1412, C, H, W) && !s16_cfg_in_stats_ok(1812, C, H, W)) return 0;
-    return (S16_IN_WS_HEAD + (size_t)B * C * 2 + (size_t)B * nct32 * npatch * 64) * sizeof(float);
+    if (B <= 0 || C <= 0 || C % 32 != 0 || H <= 0 || W <= 0 || (long long)4 * H * W > (1 << 20)) return 0;    // (s16_deconv_sums: 63-bit sums)
+    return (size_t)B * C * 2 * sizeof(long long);
 }
 
 size_t tcs_s16_bytes(int B, int C, int H, int W) {
@@ -982,8 +884,8 @@ int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
         if (d->epilogue != TCS_EPI_LINEAR || (!a.out16 && !a.tap_out) || a.out16_split <= 0 || a.out16_split % 32 != 0 || a.out16_split >= d->Cout) return TCS_EINVAL;
         if (a.out16b_groups < (d->Cout - a.out16_split + 7) / 8) return TCS_EINVAL;
     }
-    a.in_ws = d->in_stats; a.in_eps = d->in_eps;
-    if (a.in_ws && (d->epilogue != TCS_EPI_DECONV2X || d->Cout % 128 != 0 || d->B > S16_IN_WS_HEAD || !(d->in_eps >= 0.f))) return TCS_EINVAL;
+    a.in_ws = d->in_stats;
+    if (a.in_ws && (d->epilogue != TCS_EPI_DECONV2X || d->Cout % 128 != 0 || (long long)4 * d->H * d->W > (1 << 20))) return TCS_EINVAL;
     a.npx = 0; a.nct = 0; a.npatch = 0;
     a.csplit = (d->tile_cfg / 100000) % 10;            // 0 = cout tile fastest (one weight slice per XCD)
     a.ablate = d->tile_cfg / 1000000;                  // honoured by -DTCS_S16_ABLATE builds only
@@ -1021,12 +923,6 @@ int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
         cfg = s16_heuristic(a, d->ksize, stride, kst, d->epilogue);
         a.csplit = cfg / 100000;
         cfg %= 100000;
-    }
-    if (a.in_ws) {                                     // fused InstanceNorm statistics: the slots must fit the last workgroup's fetch
-        if (!s16_cfg_in_stats_ok(cfg, d->Cout / 4, d->H, d->W)) {
-            if (d->tile_cfg % 100000 != 0 || !s16_cfg_in_stats_ok(1812, d->Cout / 4, d->H, d->W)) return TCS_EUNSUPPORTED;
-            cfg = 1812;                                // the heuristic's tile does not, the 8-row two-stage tile does
-        }
     }
     if (a.nct32 % ((cfg / 1000) % 10) != 0) return TCS_EUNSUPPORTED;          // the cout tile must divide the packed tiles
 

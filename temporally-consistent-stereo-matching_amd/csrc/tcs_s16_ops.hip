@@ -180,11 +180,11 @@ __global__ __launch_bounds__(INS_T) void k_in_apply_s16(const _Float16* __restri
     s16_store8(out + (((size_t)b * Go + g) * 2) * plane + u, plane, v);
 }
 
-// the apply half for statistics that the producing transposed convolution already reduced (tcs_conv_s16.hip: s16_deconv_stats):
-// finals = [B][C][2] (mean, 1/sqrt(var + eps)); one thread per unit, no merge loop
-__global__ __launch_bounds__(INS_T) void k_in_apply_final_s16(const _Float16* __restrict__ x, int Gt, int G, int H, int W, int C,
-                                                               const float* __restrict__ finals, int act,
-                                                               const _Float16* __restrict__ addend, int Ga, _Float16* __restrict__ out, int Go) {
+// the apply half for statistics that the producing transposed convolution accumulated (tcs_conv_s16.hip: s16_deconv_sums):
+// sums = [B][C][2] 64-bit fixed point (sum x * 2^20, sum x^2 * 2^16) over the H*W pixels; one thread per unit, no merge loop
+__global__ __launch_bounds__(INS_T) void k_in_apply_sums_s16(const _Float16* __restrict__ x, int Gt, int G, int H, int W, int C,
+                                                              const long long* __restrict__ sums, float eps, int act,
+                                                              const _Float16* __restrict__ addend, int Ga, _Float16* __restrict__ out, int Go) {
     const int b = blockIdx.y / G, g = blockIdx.y - b * G, bg = b * Gt + g;      // G = C/8 real groups of a tensor with Gt groups
     const int HW = H * W, Wp = W + 2;
     const size_t plane = (size_t)(H + 2) * Wp * 8;
@@ -195,13 +195,16 @@ __global__ __launch_bounds__(INS_T) void k_in_apply_final_s16(const _Float16* __
     float v[8], t[8];
     s16_load8(x + ((size_t)bg * 2) * plane + u, plane, v);
     if (addend) s16_load8(addend + (((size_t)b * Ga + g) * 2) * plane + u, plane, t);
-    const float4* f = reinterpret_cast<const float4*>(finals + ((size_t)b * C + min(g * 8, C - 8)) * 2);      // wave-uniform
-    const float4 f0 = f[0], f1 = f[1], f2 = f[2], f3 = f[3];
-    const float mean[8] = {f0.x, f0.z, f1.x, f1.z, f2.x, f2.z, f3.x, f3.z}, rstd[8] = {f0.y, f0.w, f1.y, f1.w, f2.y, f2.w, f3.y, f3.w};
+    const long long* sp = sums + ((size_t)b * C + min(g * 8, C - 8)) * 2;      // wave-uniform: 16 scalar-cache loads
+    const double inv_n = 1.0 / (double)HW;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
+        // mean and E[x^2] from the integer sums in double (two conversions and three multiplications per channel: exact to 2^-53, so
+        // that E[x^2] - mean^2 loses nothing the sums still had)
+        const double mu = (double)sp[2 * j] * (inv_n / 1048576.0), ex2 = (double)sp[2 * j + 1] * (inv_n / 65536.0);
+        const float mean = (float)mu, rstd = 1.0f / sqrtf(fmaxf((float)(ex2 - mu * mu), 0.f) + eps);
         const bool real = g * 8 + j < C;                   // padding channels of the last group stay zero
-        v[j] = real ? s16_act((v[j] - mean[j]) * rstd[j], act) + (addend ? t[j] : 0.f) : 0.f;
+        v[j] = real ? s16_act((v[j] - mean) * rstd, act) + (addend ? t[j] : 0.f) : 0.f;
         if (act == TCS_ACT_RELU_ADD_RELU) v[j] = fmaxf(v[j], 0.f);
     }
     s16_store8(out + (((size_t)b * Go + g) * 2) * plane + u, plane, v);
@@ -394,14 +397,15 @@ int tcs_instance_norm_s16(const void* x, int B, int groups, int H, int W, float 
 }
 
 int tcs_instance_norm_apply_s16(const void* x, int B, int groups, int H, int W, int act, const void* addend, int addend_groups,
-                                void* out, int out_groups, const float* in_stats, int C, tcs_stream_t stream) {
-    if (!x || !out || !in_stats || B <= 0 || B > 16 || groups <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 32 != 0 || groups * 8 < C) return TCS_EINVAL;
+                                void* out, int out_groups, const void* in_stats, int C, float eps, tcs_stream_t stream) {
+    if (!x || !out || !in_stats || B <= 0 || groups <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 32 != 0 || groups * 8 < C || !(eps >= 0.f)) return TCS_EINVAL;
+    if ((long long)B * (C / 8) > 65535 || (long long)H * W > (1 << 20)) return TCS_EUNSUPPORTED;
     if (act != TCS_ACT_NONE && act != TCS_ACT_RELU && act != TCS_ACT_LEAKY && act != TCS_ACT_RELU_ADD_RELU) return TCS_EUNSUPPORTED;
     if (act == TCS_ACT_RELU_ADD_RELU && !addend) return TCS_EINVAL;
     if (out_groups != groups || (addend && addend_groups != groups)) return TCS_EUNSUPPORTED;
     const int G = C / 8;                                   // real groups (C % 32 == 0: no partial group)
-    hipLaunchKernelGGL(k_in_apply_final_s16, dim3(tcs_cdiv((long long)H * W, INS_T), B * G), dim3(INS_T), 0, tcs_stream(stream),
-                       reinterpret_cast<const _Float16*>(x), groups, G, H, W, C, in_stats + 16 /* S16_IN_WS_HEAD */, act,
+    hipLaunchKernelGGL(k_in_apply_sums_s16, dim3(tcs_cdiv((long long)H * W, INS_T), B * G), dim3(INS_T), 0, tcs_stream(stream),
+                       reinterpret_cast<const _Float16*>(x), groups, G, H, W, C, reinterpret_cast<const long long*>(in_stats), eps, act,
                        reinterpret_cast<const _Float16*>(addend), addend_groups, reinterpret_cast<_Float16*>(out), out_groups);
     return tcs_launch_status();
 }

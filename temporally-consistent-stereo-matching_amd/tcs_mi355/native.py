@@ -110,7 +110,7 @@ SIGNATURES = {
     "tcs_instance_norm_s16_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
     "tcs_instance_norm_s16": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_f, c_int, c_fp, c_int, c_fp, c_int, c_fp, c_fp]),
     "tcs_deconv_in_stats_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
-    "tcs_instance_norm_apply_s16": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_int, c_fp, c_int, c_fp, c_int, c_fp]),
+    "tcs_instance_norm_apply_s16": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_fp, c_int, c_fp, c_int, c_fp, c_int, c_f, c_fp]),
     "tcs_tap_weights_floats": (c_sz, [c_int, c_int]),
     "tcs_pack_tap_weights": (c_int, [c_fp, c_int, c_int, c_int, c_fp, c_fp]),
     "tcs_taps_sum": (c_int, [c_fp, c_int, c_int, c_fp, c_fp, c_f, c_int, c_int, c_int, c_fp, c_fp]),

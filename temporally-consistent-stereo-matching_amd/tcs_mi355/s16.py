@@ -92,8 +92,16 @@ class S16Pool:
             buf = self.buffers[k] = (torch.zeros if zero else torch.empty)(*k[1], dtype=torch.float32, device=device)
         return buf
 
+    def get_i64(self, key, shape, device) -> torch.Tensor:
+        """A persistent zero-initialised int64 tensor (the fixed-point InstanceNorm sums of the fused transposed convolutions)."""
+        k = (key, tuple(int(v) for v in shape), "i64", str(device))
+        buf = self.buffers.get(k)
+        if buf is None:
+            buf = self.buffers[k] = torch.zeros(*k[1], dtype=torch.int64, device=device)
+        return buf
+
     def bytes(self) -> int:
-        return sum((b.data if isinstance(b, S16) else b).numel() * (2 if isinstance(b, S16) else 4) for b in self.buffers.values())
+        return sum((b.data if isinstance(b, S16) else b).numel() * (b.data if isinstance(b, S16) else b).element_size() for b in self.buffers.values())
 
 
 def to_s16(x: torch.Tensor, out: Optional[S16] = None, group_offset: int = 0) -> S16:
@@ -209,22 +217,23 @@ def conv2d(pc: PackedConv, srcs: Sequence[S16], act: str = "none", addend: Optio
 def deconv_in_stats_ok(B: int, cout: int, H: int, W: int) -> bool:
     """Can the transposed convolution compute the InstanceNorm statistics of its own output (tcs_conv_s16_desc.in_stats) at this
     size ([H, W] = its INPUT grid)?"""
-    return cout % 32 == 0 and B <= 16 and nv.lib().tcs_deconv_in_stats_bytes(int(B), int(cout), int(H), int(W)) > 0
+    return cout % 32 == 0 and nv.lib().tcs_deconv_in_stats_bytes(int(B), int(cout), int(H), int(W)) > 0
 
 
 def deconv_in_stats_workspace(B: int, cout: int, H: int, W: int, device) -> torch.Tensor:
-    """Zero-filled workspace for `deconv4x4s2(..., in_stats=)`: ticket counters, per-channel (mean, rstd), per-workgroup slots.
-    [H, W] is the transposed convolution's INPUT grid.  Allocate once and keep (the launches re-arm the counters)."""
+    """Zero-filled accumulators for ONE `deconv4x4s2(..., in_stats=)` launch: int64 [B, cout, 2] = fixed-point (sum x, sum x^2) of its
+    output.  [H, W] is the transposed convolution's INPUT grid.  The launch ADDS: zero the tensor again before it is reused."""
     n = nv.lib().tcs_deconv_in_stats_bytes(int(B), int(cout), int(H), int(W))
     if n == 0:
-        raise ValueError("deconv_in_stats_workspace: needs cout % 32 == 0 and B <= 16")
-    return torch.zeros(n // 4, dtype=torch.float32, device=device)
+        raise ValueError("deconv_in_stats_workspace: needs cout % 32 == 0 and an output grid of at most 2^20 pixels")
+    return torch.zeros(int(B), int(cout), 2, dtype=torch.int64, device=device)
 
 
 def deconv4x4s2(pc: PackedConv, srcs: Sequence[S16], out16: Optional[S16] = None, act: str = "none", tile_cfg: int = 0,
                 in_stats: Optional[torch.Tensor] = None, eps: float = 1e-5) -> S16:
     """ConvTranspose2d(k=4, s=2, p=1, no bias) (+ activation): S16 [B,Cin,H,W] -> S16 [B,Cout,2H,2W].  With `in_stats`
-    (deconv_in_stats_workspace) the launch also leaves InstanceNorm2d's (mean, rstd) of its output there, for `instance_norm_apply`."""
+    (deconv_in_stats_workspace: int64 [B, Cout, 2], ZERO before the launch) the launch also accumulates the sums InstanceNorm2d needs of its
+    output there, for `instance_norm_apply`."""
     d = _desc(pc, srcs)
     cout = pc.cout // 4
     if out16 is None:
@@ -234,24 +243,27 @@ def deconv4x4s2(pc: PackedConv, srcs: Sequence[S16], out16: Optional[S16] = None
     d.epilogue, d.act = EPI_DECONV2X, ACT[act]
     d.out16, d.out16_groups, d.out16_group_offset = out16.ptr(), out16.G, 0
     if in_stats is not None:
-        if in_stats.numel() * 4 < nv.lib().tcs_deconv_in_stats_bytes(d.B, cout, d.H, d.W):
-            raise ValueError("deconv4x4s2: `in_stats` workspace too small for this layer")
-        d.in_stats, d.in_eps = nv.ptr(in_stats, "in_stats"), float(eps)
+        need = nv.lib().tcs_deconv_in_stats_bytes(d.B, cout, d.H, d.W)
+        if need == 0 or in_stats.dtype != torch.int64 or in_stats.numel() * 8 < need:
+            raise ValueError("deconv4x4s2: `in_stats` must be an int64 tensor of [B, Cout, 2] (deconv_in_stats_workspace)")
+        d.in_stats, d.in_eps = nv.ptr(in_stats, "in_stats", torch.int64), float(eps)
     d.tile_cfg = int(tile_cfg)
     nv.check(nv.lib().tcs_conv2d_s16(C.byref(d), nv.stream()), "tcs_conv2d_s16[deconv2x]")
     return out16
 
 
-def instance_norm_apply(x: S16, in_stats: torch.Tensor, act: str = "none", addend: Optional[S16] = None, out: Optional[S16] = None) -> S16:
-    """act((x - mean) * rstd) + addend with the statistics the producing `deconv4x4s2(..., in_stats=)` left behind; `out` may be `x`."""
+def instance_norm_apply(x: S16, in_stats: torch.Tensor, act: str = "none", addend: Optional[S16] = None, out: Optional[S16] = None,
+                        eps: float = 1e-5) -> S16:
+    """act((x - mean) * rstd) + addend with the sums the producing `deconv4x4s2(..., in_stats=)` accumulated; `out` may be `x`."""
     out = zeros(x.B, x.C, x.H, x.W, x.device, x.G) if out is None else out
     if addend is not None and (addend.B, addend.H, addend.W, addend.G) != (x.B, x.H, x.W, x.G):
         raise ValueError("instance_norm_apply: bad addend")
     if (out.B, out.H, out.W, out.G) != (x.B, x.H, x.W, x.G):
         raise ValueError("instance_norm_apply: bad `out`")
     nv.check(nv.lib().tcs_instance_norm_apply_s16(x.ptr(), x.B, x.G, x.H, x.W, ACT[act], None if addend is None else addend.ptr(),
-                                                  0 if addend is None else addend.G, out.ptr(), out.G, nv.ptr(in_stats, "in_stats"), x.C,
-                                                  nv.stream()), "tcs_instance_norm_apply_s16")
+                                                  0 if addend is None else addend.G, out.ptr(), out.G,
+                                                  nv.ptr(in_stats, "in_stats", torch.int64), x.C, float(eps), nv.stream()),
+             "tcs_instance_norm_apply_s16")
     return out
 
 
