@@ -199,9 +199,10 @@ def up_block16(pool, block: Conv2x_IN, x: s16.S16, rem: s16.S16, slot=None) -> s
 
 
 def up_block_sums(pool, block: Conv2x_IN, B: int, device) -> torch.Tensor:
-    """int64 [IN_SUM_SLOTS, B, C, 2]: the fixed-point InstanceNorm accumulators of `up_block16(..., slot=)` for this block."""
+    """int64 [IN_SUM_SLOTS, B, C, stride]: the fixed-point InstanceNorm accumulators of `up_block16(..., slot=)` for this block."""
     dc = block.conv1.conv
-    return pool.get_i64((id(dc), "in_sums"), (IN_SUM_SLOTS, int(B), dc.out_channels, 2), device)
+    stride = s16.nv.lib().tcs_deconv_in_stats_bytes(1, dc.out_channels, 8, 8) // (8 * dc.out_channels)       # 64-bit words per channel
+    return pool.get_i64((id(dc), "in_sums"), (IN_SUM_SLOTS, int(B), dc.out_channels, stride), device)
 
 
 def hip_conv(conv, srcs, act="none", **kw):

@@ -322,7 +322,7 @@ __device__ __forceinline__ void s16_deconv_sums(const S16Args& a, int b, int ct,
                                                 const f32x16* acc, float* lds /* >= ROWS * 64 floats, free to use */) {
     const int C = a.hidden, l31 = lane & 31, half = lane >> 5;
     const bool valid = px < a.W && py < a.H;
-    unsigned long long* sums = reinterpret_cast<unsigned long long*>(a.in_ws) + (size_t)b * C * 2;
+    unsigned long long* sums = reinterpret_cast<unsigned long long*>(a.in_ws) + (size_t)b * C * S16_IN_STRIDE;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         float s1[16], s2[16];
@@ -370,8 +370,8 @@ __device__ __forceinline__ void s16_deconv_sums(const S16Args& a, int b, int ct,
             if (cout < a.Cout) {
                 const int c = cout % C;
                 const long long q1 = __float2ll_rn(t1 * S16_IN_SCALE_SUM), q2 = __float2ll_rn(t2 * S16_IN_SCALE_SQ);
-                __hip_atomic_fetch_add(sums + c * 2 + 0, (unsigned long long)q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(sums + c * 2 + 1, (unsigned long long)q2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(sums + c * S16_IN_STRIDE + 0, (unsigned long long)q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(sums + c * S16_IN_STRIDE + 1, (unsigned long long)q2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -808,7 +808,7 @@ extern "C" {
 
 size_t tcs_deconv_in_stats_bytes(int B, int C, int H, int W) {
     if (B <= 0 || C <= 0 || C % 32 != 0 || H <= 0 || W <= 0 || (long long)4 * H * W > (1 << 20)) return 0;    // (s16_deconv_sums: 63-bit sums)
-    return (size_t)B * C * 2 * sizeof(long long);
+    return (size_t)B * C * S16_IN_STRIDE * sizeof(long long);
 }
 
 size_t tcs_s16_bytes(int B, int C, int H, int W) {

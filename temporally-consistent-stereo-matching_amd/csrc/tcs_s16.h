@@ -8,6 +8,12 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
+// Fixed-point InstanceNorm accumulators of the fused transposed convolutions (tcs_conv_s16.hip: s16_deconv_sums, tcs_s16_ops.hip:
+// k_in_apply_sums_s16): S16_IN_STRIDE 64-bit words per (b, channel), words 0 and 1 = sum x * 2^20, sum x^2 * 2^16.
+#ifndef S16_IN_STRIDE
+#define S16_IN_STRIDE 2
+#endif
+
 // Domain guard of the split: |x| <= 65504.  A value outside it is clamped (a NaN becomes 65504) and leaves a mark in a
 // device-side flag word that the host can read once per frame (tcs_s16_flags): bit 0 = a finite value was saturated,
 // bit 1 = a non-finite value was seen.  One flag word per translation unit that includes this header (no relocatable

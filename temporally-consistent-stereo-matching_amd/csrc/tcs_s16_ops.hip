@@ -195,13 +195,13 @@ __global__ __launch_bounds__(INS_T) void k_in_apply_sums_s16(const _Float16* __r
     float v[8], t[8];
     s16_load8(x + ((size_t)bg * 2) * plane + u, plane, v);
     if (addend) s16_load8(addend + (((size_t)b * Ga + g) * 2) * plane + u, plane, t);
-    const long long* sp = sums + ((size_t)b * C + min(g * 8, C - 8)) * 2;      // wave-uniform: 16 scalar-cache loads
+    const long long* sp = sums + ((size_t)b * C + min(g * 8, C - 8)) * S16_IN_STRIDE;      // wave-uniform: 16 scalar-cache loads
     const double inv_n = 1.0 / (double)HW;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         // mean and E[x^2] from the integer sums in double (two conversions and three multiplications per channel: exact to 2^-53, so
         // that E[x^2] - mean^2 loses nothing the sums still had)
-        const double mu = (double)sp[2 * j] * (inv_n / 1048576.0), ex2 = (double)sp[2 * j + 1] * (inv_n / 65536.0);
+        const double mu = (double)sp[S16_IN_STRIDE * j] * (inv_n / 1048576.0), ex2 = (double)sp[S16_IN_STRIDE * j + 1] * (inv_n / 65536.0);
         const float mean = (float)mu, rstd = 1.0f / sqrtf(fmaxf((float)(ex2 - mu * mu), 0.f) + eps);
         const bool real = g * 8 + j < C;                   // padding channels of the last group stay zero
         v[j] = real ? s16_act((v[j] - mean) * rstd, act) + (addend ? t[j] : 0.f) : 0.f;

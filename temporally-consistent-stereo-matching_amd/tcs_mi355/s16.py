@@ -221,12 +221,12 @@ def deconv_in_stats_ok(B: int, cout: int, H: int, W: int) -> bool:
 
 
 def deconv_in_stats_workspace(B: int, cout: int, H: int, W: int, device) -> torch.Tensor:
-    """Zero-filled accumulators for ONE `deconv4x4s2(..., in_stats=)` launch: int64 [B, cout, 2] = fixed-point (sum x, sum x^2) of its
-    output.  [H, W] is the transposed convolution's INPUT grid.  The launch ADDS: zero the tensor again before it is reused."""
+    """Zero-filled accumulators for ONE `deconv4x4s2(..., in_stats=)` launch: int64 [B, cout, stride >= 2], [..., 0:2] = fixed-point
+    (sum x, sum x^2) of its output.  [H, W] is the transposed convolution's INPUT grid.  The launch ADDS: zero the tensor again before it is reused."""
     n = nv.lib().tcs_deconv_in_stats_bytes(int(B), int(cout), int(H), int(W))
     if n == 0:
         raise ValueError("deconv_in_stats_workspace: needs cout % 32 == 0 and an output grid of at most 2^20 pixels")
-    return torch.zeros(int(B), int(cout), 2, dtype=torch.int64, device=device)
+    return torch.zeros(int(B), int(cout), n // (8 * int(B) * int(cout)), dtype=torch.int64, device=device)
 
 
 def deconv4x4s2(pc: PackedConv, srcs: Sequence[S16], out16: Optional[S16] = None, act: str = "none", tile_cfg: int = 0,
