@@ -297,6 +297,10 @@ class TCStereo(nn.Module):
         # 27.0 against 26.4 ms per frame (3 rounds each) — the early launch (128 -> 256 at 1/4 scale, 41 us alone) competes with the
         # encoder and the coarse GRUs for the CUs, and a fifth stream shares one of the four hardware queues (profiles/r03_ab_logs.txt)
         g08split = "g08split" in _X and trace is None and a.n_gru_layers >= 2
+        # ... and (token "g08m") the MOTION third instead, on the encoder's own queue right behind the encoder, in the ~30 us that queue
+        # waits for the coarse branch: no extra stream, no extra dependency — 26.56 against 26.46 ms (3 rounds each): the extra launch and
+        # the fp32 partial sums' 20 MB each way cost what the shorter late launch saves.  Off.
+        g08m = "g08m" in _X and not g08split and trace is None and a.n_gru_layers >= 2
         for itr in range(iters):
             # Two independent chains open an iteration: [hidden-state update of the previous iteration -> gru32 -> gru16 ->
             # interp] needs only the hidden states; [corr lookup -> motion encoder] needs only coords1 / the flow written by the
@@ -304,7 +308,10 @@ class TCStereo(nn.Module):
             # share of gru16 that reads only net16 / interp(net32) run ahead, beside gru08 / flow head / refinement (update.py).
             def enc_branch():
                 corr = corr_fn(coords1)
-                return corr, ub.encoder.run(pool, flows_x, corr, motion)
+                mf = ub.encoder.run(pool, flows_x, corr, motion)
+                if g08m:         # the motion third of gru08's gate convolution, in the slot where this queue would wait for the coarse branch
+                    return corr, mf, ub.gru08_early(pool, nets, inp_list, motion=mf)
+                return corr, mf
 
             def coarse_branch():
                 if hu_delta is not None:
@@ -328,6 +335,8 @@ class TCStereo(nn.Module):
             if g08split:
                 hu_done = torch.cuda.Event()
                 (corr, m), up16, zr_early = fork_join([enc_branch, coarse_branch, early08_branch], site="iter")
+            elif g08m:
+                (corr, m, zr_early), up16 = fork_join([enc_branch, coarse_branch], site="iter")
             else:
                 ((corr, m), up16), zr_early = fork_join([enc_branch, coarse_branch], site="iter"), None
             if plain and trace is None and itr + 1 < iters:
@@ -338,7 +347,7 @@ class TCStereo(nn.Module):
                 early32 = spawn(ahead, site="gru32")
             sums = getattr(self, "_checksums", None)       # debugging hook (tools/determinism_check.py): device-side sums, no sync
             lazy = trace is None and sums is None           # the hooks want the flow head's / residual head's outputs as tensors
-            delta_flow = ub.run_fine(pool, nets, inp_list, m, up16, lazy=lazy, zr_early=zr_early)
+            delta_flow = ub.run_fine(pool, nets, inp_list, m, up16, lazy=lazy, zr_early=zr_early, early_motion=g08m and zr_early is not None)
             # disp_q = x - (coords1 + delta), 5 * disp2disp_gradient_xy (update.py:199) and the gradient candidates in one
             # launch (with the flow head's last convolution finished from its tap partials); coords1 is replaced by the blend
             # kernel's output below

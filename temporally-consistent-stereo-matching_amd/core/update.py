@@ -532,9 +532,10 @@ class BasicMultiUpdateBlock(nn.Module):
     # ---- gru08's gate convolution split the same way: net08 is final once the hidden-state update of the previous iteration has run,
     # ~70 us before the motion features and interp(net16) arrive; its third of conv_zr's input channels (context addends and bias
     # included) is contracted then, on a third parallel branch, and the launch on the critical chain is a K = 256 convolution ----
-    def gru08_early(self, pool, net, inp):
-        """-> fp32 [B, 2*hidden, H, W] partial sums of gru08.convzr over the hidden-state channels + cat(cz, cr) + bias, or None when
-        the context tensors are not the three thirds of one tensor (then run_fine contracts everything at once)."""
+    def gru08_early(self, pool, net, inp, motion=None):
+        """-> fp32 [B, 2*hidden, H, W] partial sums of gru08.convzr over the hidden-state channels (or, with `motion`, over the motion
+        features' channels) + cat(cz, cr) + bias, or None when the context tensors are not the three thirds of one tensor (then run_fine
+        contracts everything at once)."""
         g, h = self.gru08, net[0]
         hid = h.C
         cz, cr, cq = inp[0]
@@ -544,12 +545,16 @@ class BasicMultiUpdateBlock(nn.Module):
             return None
         czr = torch.as_strided(cz, (h.B, 2 * hid, h.H, h.W), cz.stride())
         p_zr = pool.get32((id(self), "p08zr"), (h.B, 2 * hid, h.H, h.W), h.device)
-        s16.conv2d(packed16_part(g.convzr, ((0, hid),)), [h], addend=czr, addend_ctot=int(cz.stride(0)) // plane, out32=p_zr)
+        if motion is not None:
+            s16.conv2d(packed16_part(g.convzr, ((hid, hid + motion.C),)), [motion], addend=czr, addend_ctot=int(cz.stride(0)) // plane, out32=p_zr)
+        else:
+            s16.conv2d(packed16_part(g.convzr, ((0, hid),)), [h], addend=czr, addend_ctot=int(cz.stride(0)) // plane, out32=p_zr)
         return p_zr
 
-    def run_fine(self, pool, net, inp, motion_features, up16, update=True, lazy=False, zr_early=None):
+    def run_fine(self, pool, net, inp, motion_features, up16, update=True, lazy=False, zr_early=None, early_motion=False):
         """gru08 on (motion features, upsampled net16) and the flow head (update.py:154-168); returns delta_flow (fp32), or with
-        `lazy` the flow head's tap partials (FlowHead.run).  `zr_early`: gru08_early's partial sums of this iteration."""
+        `lazy` the flow head's tap partials (FlowHead.run).  `zr_early`: gru08_early's partial sums of this iteration (`early_motion`:
+        taken over the motion features instead of the hidden state)."""
         xs = [motion_features] + ([up16] if up16 is not None else [])
         if zr_early is None:
             self.gru08.step16(pool, net[0], xs, *inp[0])
@@ -558,8 +563,14 @@ class BasicMultiUpdateBlock(nn.Module):
             hid, cq = h.C, inp[0][2]
             z = pool.get32((id(g), "z"), (h.B, hid, h.H, h.W), h.device)
             rh = pool.get((id(g), "rh"), h.B, hid, h.H, h.W, h.device)
-            s16.gru_gates(packed16_part(g.convzr, ((hid, hid + sum(x.C for x in xs)),), with_bias=False), xs, h, zr_early[:, :hid],
-                          zr_early[:, hid:], z_out=z, rh_out=rh, addend_ctot=2 * hid)
+            if early_motion:                        # the late share: hidden state + interp(net16)
+                m_c = motion_features.C
+                late = ((0, hid),) + (((hid + m_c, hid + m_c + up16.C),) if up16 is not None else ())
+                s16.gru_gates(packed16_part(g.convzr, late, with_bias=False), [h] + xs[1:], h, zr_early[:, :hid], zr_early[:, hid:], z_out=z,
+                              rh_out=rh, addend_ctot=2 * hid)
+            else:
+                s16.gru_gates(packed16_part(g.convzr, ((hid, hid + sum(x.C for x in xs)),), with_bias=False), xs, h, zr_early[:, :hid],
+                              zr_early[:, hid:], z_out=z, rh_out=rh, addend_ctot=2 * hid)
             s16.gru_update(packed16(g.convq), [rh, *xs], h, z, cq, keep_z=g.keep_z, out=h,
                            addend_ctot=0 if cq.is_contiguous() else int(cq.stride(0)) // (h.H * h.W))
         return self.flow_head.run(pool, net[0], lazy=lazy) if update else None
