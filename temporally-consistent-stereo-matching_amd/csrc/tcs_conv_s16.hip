@@ -755,7 +755,7 @@ static int launch_s16_cfg(S16Args& a, int cfg, hipStream_t s) {
         }
     } else if constexpr (KS == 3) {
         switch (cfg) {
-            S16_CASE(1, 4, 1, 2)
+            S16_CASE(1, 4, 1, 2) S16_CASE(1, 4, 1, 1)
             default: return TCS_EUNSUPPORTED;
         }
     } else if constexpr (STRIDE == 2) {                 // 1x1 stride 2 (the projection shortcut of a down-sampling residual block)
@@ -787,7 +787,14 @@ static int s16_heuristic(const S16Args& a, int ksize, int stride, int kst1x1, in
         const int mt = (a.nct32 % 2 == 0 && a.nct32 >= 8) ? 2 : 1;
         return 100000 + mt * 1000 + 400 + kst1x1 * 10 + 2;
     }
-    if (stride == 2) return 1412;
+    if (stride == 2) {
+        // 3x3 stride 2: the stage is 37 + 18 KiB (a 9 x 65 input window per k-step).  Two stages = one workgroup per CU; on grids of more
+        // than one workgroup per CU ONE stage (two per CU, hiding each other's fills) wins: feature extractor 480x640 -> 240x320
+        // 180.6 -> 125.5 us, 240x320 -> 120x160 73.2 -> 48.7; the loop's small grids keep two stages.  All cout tiles of a patch on one
+        // XCD (CSPLIT = 1) either way: 16.1 -> 13.8 us at 1/4 -> 1/8 scale (profiles/r03_conv_s16_stride2_sweep.txt)
+        const long long blocks4 = (long long)tcs_cdiv(a.W, 32) * tcs_cdiv(a.H, 4) * a.B * a.nct32;
+        return blocks4 > 256 ? 101411 : 101412;
+    }
     const long long blocks8 = (long long)tcs_cdiv(a.W, 32) * tcs_cdiv(a.H, 8) * a.B * a.nct32;
     if (blocks8 >= 280) {
         // 1/4-scale grids: the long, wide layers (gru08.zr) keep 8-row patches with two stages; everything else runs as 4-row

@@ -33,6 +33,10 @@ SHAPES = [  # name, (cins...), cout, k, H, W, epilogue, stride
     ("head 256->1", (256,), 1, 3, 120, 160, "lin", 1),
     ("head 128->2", (128,), 2, 3, 120, 160, "lin", 1),
     ("s2 64->96", (64,), 96, 3, 120, 160, "lin", 2),
+    ("s2 96->128/8", (96,), 128, 3, 60, 80, "lin", 2),          # gradient predictor, 1/8 -> 1/16
+    ("s2 quarter 128->128", (128,), 128, 3, 120, 160, "lin", 2),  # context / feature pyramid, 1/4 -> 1/8 (BATCH=2 for the shared trunk)
+    ("s2 full 64->96", (64,), 96, 3, 480, 640, "lin", 2),       # feature extractor, first convolution of layer2 (run with BATCH=2)
+    ("s2 half 96->128", (96,), 128, 3, 240, 320, "lin", 2),     # ... of layer3
     ("full 64->64", (64,), 64, 3, 480, 640, "lin", 1),          # feature extractor, layer1 at full resolution (run with BATCH=2)
     ("half 96->96", (96,), 96, 3, 240, 320, "lin", 1),          # layer2
     ("quarter 128->128", (128,), 128, 3, 120, 160, "lin", 1),   # layer3 / heads
