@@ -782,7 +782,9 @@ static int launch_s16_cfg(S16Args& a, int cfg, hipStream_t s) {
 //  * 1x1: two k-steps per stage; 64-channel tiles for Cout >= 256;
 //  * CSPLIT = 1 (all cout tiles of a patch on one XCD, s16_block_tile): 0-3 % on 3x3, 20-30 % on the 1x1 layers.
 static int s16_heuristic(const S16Args& a, int ksize, int stride, int kst1x1, int epilogue) {
-    if (ksize == 1 && stride == 2) return 1000 + 400 + kst1x1 * 10 + 2;
+    // strided 1x1 (projection shortcuts): one k-step per stage, all cout tiles of a patch on one XCD — 74.6 -> 56.5 us at 480x640 ->
+    // 240x320 (two images), 31.6 -> 18.6 one level down (profiles/r03_conv_s16_stride2_sweep.txt)
+    if (ksize == 1 && stride == 2) return 100000 + 1000 + 400 + 10 + 2;
     if (ksize == 1) {
         const int mt = (a.nct32 % 2 == 0 && a.nct32 >= 8) ? 2 : 1;
         return 100000 + mt * 1000 + 400 + kst1x1 * 10 + 2;

@@ -35,6 +35,8 @@ SHAPES = [  # name, (cins...), cout, k, H, W, epilogue, stride
     ("s2 64->96", (64,), 96, 3, 120, 160, "lin", 2),
     ("s2 96->128/8", (96,), 128, 3, 60, 80, "lin", 2),          # gradient predictor, 1/8 -> 1/16
     ("s2 quarter 128->128", (128,), 128, 3, 120, 160, "lin", 2),  # context / feature pyramid, 1/4 -> 1/8 (BATCH=2 for the shared trunk)
+    ("1x1s2 full 64->96", (64,), 96, 1, 480, 640, "lin", 2),    # feature extractor, projection shortcut of layer2 (BATCH=2)
+    ("1x1s2 half 96->128", (96,), 128, 1, 240, 320, "lin", 2),  # ... of layer3
     ("s2 full 64->96", (64,), 96, 3, 480, 640, "lin", 2),       # feature extractor, first convolution of layer2 (run with BATCH=2)
     ("s2 half 96->128", (96,), 128, 3, 240, 320, "lin", 2),     # ... of layer3
     ("full 64->64", (64,), 64, 3, 480, 640, "lin", 1),          # feature extractor, layer1 at full resolution (run with BATCH=2)
@@ -120,8 +122,11 @@ for name, cins, cout, k, H, W, epi, stride in SHAPES:
             outs.update(o16=s16.zeros(NB, cout, o32.shape[2], o32.shape[3], dev), o32=o32)
         return (o32,)
 
-    ref = [t.clone() for t in old()]
-    t_old = timed(old)
+    try:
+        ref = [t.clone() for t in old()]
+        t_old = timed(old)
+    except NotImplementedError:                  # (the fp32-tensor kernels have no 1x1 stride-2 variant: timing only, checked against cfg 0)
+        ref, t_old = None, float("nan")
     macs = NB * ((H - 1) // stride + 1) * ((W - 1) // stride + 1) * cin * cout * k * k
     line = f"{name:16s} {H}x{W} cin {cin:4d} cout {cout:4d}: old {t_old:7.1f} us {2.0 * macs / t_old / 1e6:6.1f} TF |"
     cfgs = forced or ([0] + (CFGS1 if k == 1 else ([1412] if stride == 2 else CFGS3)))
@@ -133,6 +138,8 @@ for name, cins, cout, k, H, W, epi, stride in SHAPES:
                 continue
             raise
         errs = []
+        if ref is None:
+            ref = [(gi.float() if isinstance(gi, s16.S16) else gi).clone() for gi in got]
         for gi, r in zip(got, ref):
             gt = gi.float() if isinstance(gi, s16.S16) else gi
             errs.append(float((gt - r).abs().max()) / max(1.0, float(r.abs().max())))
