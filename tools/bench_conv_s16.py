@@ -18,6 +18,8 @@ SHAPES = [  # name, (cins...), cout, k, H, W, epilogue, stride
     ("conv128->256", (128,), 256, 3, 120, 160, "lin", 1),
     ("conv192->128", (96, 96), 128, 3, 120, 160, "lin", 1),
     ("conv128->128", (128,), 128, 3, 120, 160, "lin", 1),
+    ("conv192->96", (128, 64), 96, 3, 120, 160, "lin", 1),      # DispRefine.context_compress[0]
+    ("conv96->96", (96,), 96, 3, 120, 160, "lin", 1),           # DispRefine.context_compress[2], the gradient predictor's stems
     ("conv64->64", (64,), 64, 3, 120, 160, "lin", 1),
     ("conv160->64", (32, 64, 64), 64, 3, 120, 160, "lin", 1),
     ("gru16.zr", (128, 128, 128), 256, 3, 60, 80, "zr", 1),
