@@ -379,15 +379,24 @@ def main():
                     help="frame size other than BASELINE configs[1]'s 480x640, e.g. 375x1242 for configs[4] (KITTI raw latency)")
     ap.add_argument("--batched-leg", type=int, default=4,
                     help="after the timed run, also time this many sequences per launch (reported under batched_leg; 0/1 = skip)")
+    ap.add_argument("--drop-in-steps", type=int, default=20,
+                    help="frames of the drop-in leg (forward() only, no prefetch call; reported under drop_in_leg; 0 = skip)")
+    ap.add_argument("--kitti-steps", type=int, default=10,
+                    help="frames of the KITTI-shape latency leg (375x1242, BASELINE configs[4]; reported under kitti_leg; 0 = skip)")
     ap.add_argument("--tartanair", default=os.environ.get("TCS_TARTANAIR_SEQ", "datasets/TartanAir/abandonedfactory/Easy/P000"),
                     help="BASELINE configs[2]: a TartanAir trajectory folder (image_left/, image_right/, depth_left/, pose_left.txt); "
                          "skipped with a logged reason when absent")
     ap.add_argument("--ckpt", default=os.environ.get("TCS_CKPT", "checkpoints/tartanair.pth"),
                     help="reference checkpoint (.pth with a 'model' state dict) for the TartanAir leg; weights-only load")
+    ap.add_argument("--quick", action="store_true",
+                    help="A/B runs (tools/ab_bench.sh): the timed region, the domain flags and the evaluation gather only — no roofline pass, "
+                         "no CPU baseline, no extra legs")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher rehearsal without a GPU: ranks, rendezvous, barrier and the statistics gather only (tests)")
     a = ap.parse_args()
 
+    if a.quick:
+        a.no_cpu_baseline, a.batched_leg, a.drop_in_steps, a.kitti_steps = True, 0, 0, 0
     global HEIGHT, WIDTH
     if a.size:
         HEIGHT, WIDTH = (int(v) for v in a.size.lower().split("x"))
@@ -455,11 +464,11 @@ def main():
     roof = None
     with torch.no_grad():
         try:
-            if rank != 0:
+            if rank != 0 or a.quick:
                 raise StopIteration                # the roofline object is rank 0's
             probe = ops.LookupProbe(dev, slots=64)
             ops.LOOKUP_PROBE = probe
-            model._graphs = None
+            model._pipeline().drop()
             runner_r = ClipRunner(model, seqs, dev, ITERS, prefetch=not a.no_prefetch)
             snaps = []
             for _ in range(2):
@@ -471,7 +480,7 @@ def main():
                 probe.reset()
             torch.cuda.synchronize()
             ops.LOOKUP_PROBE = None
-            model._graphs = None                   # later legs capture without stamps again
+            model._pipeline().drop()               # later legs capture without stamps again
             roof = lookup_roofline(probe, snaps, lookup_burst_us(dev, S), S * _quarter(HEIGHT) * _quarter(WIDTH))
         except StopIteration:
             pass
@@ -534,7 +543,7 @@ def main():
               flags_b = s16.take_flags()
               # stamped pass for the lookup's in-frame duration at this batch size
               ops.LOOKUP_PROBE = probe_b = ops.LookupProbe(dev, slots=64)
-              model._graphs = None
+              model._pipeline().drop()
               runner_s = ClipRunner(model, seqs_b, dev, ITERS, prefetch=not a.no_prefetch)
               snaps_b = []
               for _ in range(2):
@@ -546,7 +555,7 @@ def main():
                   probe_b.reset()
               torch.cuda.synchronize()
               ops.LOOKUP_PROBE = None
-              model._graphs = None
+              model._pipeline().drop()
               roof_b = lookup_roofline(probe_b, snaps_b, lookup_burst_us(dev, Sb), Sb * _quarter(HEIGHT) * _quarter(WIDTH))
           batched = {"seqs_per_gpu": Sb, "value": round(a.steps * Sb / tb, 4), "unit": "stereo-pairs/s",
                      "ms_per_step": round(1e3 * tb / a.steps, 3), "domain_flags": flags_b,
@@ -556,6 +565,76 @@ def main():
         log(f"batched leg failed: {type(e).__name__}: {e}")
         batched = {"seqs_per_gpu": a.batched_leg, "error": f"{type(e).__name__}: {e}"}
         ops.LOOKUP_PROBE = None
+
+    # extra leg: exactly the calls evaluate_stereo.py:170-197 makes — forward() per frame, nothing else (no prefetch of the next frame)
+    drop_in = None
+    if rank == 0 and world == 1 and S == 1 and not a.no_prefetch and a.drop_in_steps > 0:
+        try:
+            log("drop-in leg: no prefetch call")
+            runner_d = ClipRunner(model, seqs, dev, ITERS, prefetch=False)
+            with torch.no_grad():
+                for _ in range(2):
+                    runner_d.step()
+                torch.cuda.synchronize()
+                td = time.perf_counter()
+                for _ in range(a.drop_in_steps):
+                    runner_d.step()
+                torch.cuda.synchronize()
+                td = time.perf_counter() - td
+            drop_in = {"value": round(a.drop_in_steps / td, 4), "unit": "stereo-pairs/s", "ms_per_step": round(1e3 * td / a.drop_in_steps, 3),
+                       "steps": a.drop_in_steps, "domain_flags": s16.take_flags(),
+                       "what": "TCStereo.forward() per frame only, as evaluate_stereo.py:170-197 calls it (no TCStereo.prefetch)"}
+            del runner_d
+        except Exception as e:
+            log(f"drop-in leg failed: {type(e).__name__}: {e}")
+            drop_in = {"error": f"{type(e).__name__}: {e}"}
+
+    # extra leg: BASELINE configs[4], KITTI-raw frame shape (1242x375 -> padded 1248x384), 32 iterations, per-frame LATENCY: every
+    # frame is bracketed by a device synchronisation (evaluate_stereo.py:85-89 times frames like that).  Captured once, with the
+    # lookup's stamps on (one atomic per wave and a store acknowledgement per lookup launch: < 0.2 % of a frame), so the same pass
+    # gives the lookup's in-frame duration at this size.
+    kitti = None
+    if rank == 0 and world == 1 and S == 1 and (HEIGHT, WIDTH) == (480, 640) and a.kitti_steps > 0:
+        try:
+            log("KITTI-shape leg: 375x1242, per-frame latency")
+            kh, kw = 375, 1242
+            seq_k = synth.make_sequence(2100, n_frames=CLIP_LEN, height=kh, width=kw, max_disp=MAX_DISP, K=synth.KITTI_K, baseline=0.54)
+            ops.LOOKUP_PROBE = probe_k = ops.LookupProbe(dev, slots=64)
+            model._pipeline().drop()
+            runner_k = ClipRunner(model, [seq_k], dev, ITERS, prefetch=False)
+            lat, snaps_k = [], []
+            with torch.no_grad():
+                for _ in range(2):
+                    runner_k.step()
+                probe_k.reset()
+                torch.cuda.synchronize()
+                for _ in range(a.kitti_steps):
+                    tk = time.perf_counter()
+                    runner_k.step()
+                    torch.cuda.synchronize()
+                    lat.append(1e3 * (time.perf_counter() - tk))
+                    snaps_k.append(probe_k.buf.clone())
+                    probe_k.reset()
+                torch.cuda.synchronize()
+            ops.LOOKUP_PROBE = None
+            model._pipeline().drop()
+            px_k = _quarter(kh) * _quarter(kw)
+            durs_k = [d for sn in snaps_k for d in probe_k.durations_us(sn)]
+            lk = float(np.mean(durs_k)) if durs_k else None
+            lat.sort()
+            kitti = {"size": "1242x375 (padded 1248x384)", "iters": ITERS, "frames": a.kitti_steps,
+                     "latency_ms_min_median_max": [round(lat[0], 3), round(lat[len(lat) // 2], 3), round(lat[-1], 3)],
+                     "pairs_per_s_from_median_latency": round(1e3 / lat[len(lat) // 2], 3), "domain_flags": s16.take_flags(),
+                     "lookup": {"algorithmic_bytes_per_launch": LOOKUP_BYTES_PER_PIXEL * px_k, "avg_launch_us": None if lk is None else round(lk, 3),
+                                "frac": None if lk is None else round(LOOKUP_BYTES_PER_PIXEL * px_k / (lk * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                "timer": "in-kernel stamps of the frame's own launches"},
+                     "what": "BASELINE configs[4] shape, synthetic frames and key-seeded weights (no KITTI data or checkpoint offline); "
+                             "host clock around forward() + device synchronisation per frame, lookup stamps on"}
+            del runner_k
+        except Exception as e:
+            log(f"KITTI leg failed: {type(e).__name__}: {e}")
+            kitti = {"error": f"{type(e).__name__}: {e}"}
+            ops.LOOKUP_PROBE = None
 
 
     # BASELINE configs[2]: real TartanAir frames + the reference's pretrained weights, only when both are on the box
@@ -575,12 +654,13 @@ def main():
                                    + ("one sequence per GPU" if S == 1 else f"{S} independent sequences batched per GPU"),
                        "frames_per_rank": a.steps * S, "seqs_per_gpu": S, "weights": "key-seeded synthetic (tcs_mi355.weights)",
                        "launch": ("eager" if a.eager else "hip-graph replay") + ("" if a.no_prefetch else
-                                  "; the next frame's image-only stage (features, correlation pyramid) starts beside the current frame's loop "
-                                  "(TCStereo.prefetch)")},
+                                  "; the next frame's image-only stage (features, correlation pyramid) is enqueued right behind the current "
+                                  "frame (TCStereo.prefetch: hides its host-side launch work; on the GPU it does not overlap the loop — DESIGN.md "
+                                  "section 6); drop_in_leg is the same run without that call")},
             "domain_flags": all_flags,
             "gathered_eval_vs_synthetic_gt": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in gathered_eval.items()},
             "roofline": roof, "cpu_baseline": cpu, "epe_vs_oracle_first_frames": epe_vs_oracle, "batched_leg": batched,
-            "tartanair_leg": real,
+            "drop_in_leg": drop_in, "kitti_leg": kitti, "tartanair_leg": real,
             "ranks_frames": [int(v[0]) for v in vecs],
             "dist_world_size": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
             "dist_backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,

@@ -288,36 +288,29 @@ class TCStereo(nn.Module):
         s16.set_channel(flows_x, motion, 127)
         ub = self.update_block
         ub.begin_frame()
-        from tcs_mi355.streams import fork_join, join, spawn
-        hu_delta = None              # the hidden-state update of iteration i-1 runs at the head of iteration i's coarse branch
-        early32 = None               # gru32 of iteration i, launched during iteration i-1 (it needs only net16 / net32)
+        from tcs_mi355 import streams as streams_mod
+        from tcs_mi355.streams import fork_join, join, mark, spawn
+        hu_delta = None              # the hidden-state update of iteration i-1 runs at the head of iteration i's coarse chain
+        early32 = None               # gru32 of iteration i + the early share of gru16, launched during iteration i-1
         plain = not a.slow_fast_gru and n3
-        # OFF by default (A/B token "g08split"): gru08's gate convolution split like gru16's — the net08 third of its input channels on a
-        # third parallel branch right after the hidden-state update, a K = 256 launch on the critical chain.  Measured on one box:
-        # 27.0 against 26.4 ms per frame (3 rounds each) — the early launch (128 -> 256 at 1/4 scale, 41 us alone) competes with the
-        # encoder and the coarse GRUs for the CUs, and a fifth stream shares one of the four hardware queues (profiles/r03_ab_logs.txt)
-        g08split = "g08split" in _X and trace is None and a.n_gru_layers >= 2
-        # ... and (token "g08m") the MOTION third instead, on the encoder's own queue right behind the encoder, in the ~30 us that queue
-        # waits for the coarse branch: no extra stream, no extra dependency — 26.56 against 26.46 ms (3 rounds each): the extra launch and
-        # the fp32 partial sums' 20 MB each way cost what the shorter late launch saves.  Off.
-        g08m = "g08m" in _X and not g08split and trace is None and a.n_gru_layers >= 2
+        # Schedule of one iteration.  The critical chain — blend(i-1) -> hidden-state update -> pool -> gru16's late
+        # share -> interp -> gru08 -> flow head -> gradient predictor -> refinement -> blend(i) — is the FIRST branch of every fork, so
+        # that it stays in one launch list of the captured graph (tcs_mi355/streams.py: MAIN_FIRST); what has slack hangs off it as side
+        # branches: [corr lookup -> motion encoder] (needs only coords1 / the flow of the previous blend, due at gru08), and [gru32 of
+        # the NEXT iteration -> the share of gru16 that reads only net16 / interp(net32)] (needs net16, due ~400 us later), which starts
+        # behind the flow head's stencil, beside the gradient predictor's small launches, not beside gru08's 600-workgroup ones.
+        # A/B tokens: "encmain" = the encoder chain first and the coarse chain as the side branch (rounds 2-3), "sp_join" = the early
+        # gru32 branch starts at the iteration's join (beside gru08) as in rounds 2-3.
+        enc_main = "encmain" in _X
+        sp_join = "sp_join" in _X
         for itr in range(iters):
-            # Two independent chains open an iteration: [hidden-state update of the previous iteration -> gru32 -> gru16 ->
-            # interp] needs only the hidden states; [corr lookup -> motion encoder] needs only coords1 / the flow written by the
-            # previous blend.  They run as parallel branches (streams.py); gru08 joins them.  gru32 of the next iteration and the
-            # share of gru16 that reads only net16 / interp(net32) run ahead, beside gru08 / flow head / refinement (update.py).
             def enc_branch():
                 corr = corr_fn(coords1)
-                mf = ub.encoder.run(pool, flows_x, corr, motion)
-                if g08m:         # the motion third of gru08's gate convolution, in the slot where this queue would wait for the coarse branch
-                    return corr, mf, ub.gru08_early(pool, nets, inp_list, motion=mf)
-                return corr, mf
+                return corr, ub.encoder.run(pool, flows_x, corr, motion)
 
             def coarse_branch():
                 if hu_delta is not None:
                     self.hiddenstate_update.run(pool, nets[0], hu_delta)
-                if g08split:
-                    hu_done.record(torch.cuda.current_stream())
                 if isinstance(up32_now, tuple):          # gru32 ran ahead together with the early share of gru16
                     return ub.gru16_late(pool, nets, up32_now[1])
                 if n3 and a.slow_fast_gru:
@@ -328,26 +321,26 @@ class TCStereo(nn.Module):
 
             up32_now = join(early32)                     # (None on the first iteration: gru32 then runs inside the coarse branch)
             early32 = None
-            def early08_branch():                        # third branch: gru08's gate convolution over net08, which is final after the
-                torch.cuda.current_stream().wait_event(hu_done)     # hidden-state update at the head of the coarse branch (enqueued first)
-                return ub.gru08_early(pool, nets, inp_list)
-
-            if g08split:
-                hu_done = torch.cuda.Event()
-                (corr, m), up16, zr_early = fork_join([enc_branch, coarse_branch, early08_branch], site="iter")
-            elif g08m:
-                (corr, m, zr_early), up16 = fork_join([enc_branch, coarse_branch], site="iter")
+            if enc_main:
+                (corr, m), up16 = fork_join([enc_branch, coarse_branch], site="iter")
             else:
-                ((corr, m), up16), zr_early = fork_join([enc_branch, coarse_branch], site="iter"), None
-            if plain and trace is None and itr + 1 < iters:
-                # net16 is final for this iteration: gru32 of the NEXT iteration runs beside gru08 / flow head / refinement
-                def ahead():
-                    up32 = ub.run_gru32(pool, nets, inp_list)
-                    return (up32, ub.gru16_early(pool, nets, inp_list, up32)) if "nog16split" not in _X else up32
-                early32 = spawn(ahead, site="gru32")
+                up16, (corr, m) = fork_join([coarse_branch, enc_branch], site="iter")
+            run_ahead = plain and trace is None and itr + 1 < iters
+            # net16 is final for this iteration: gru32 of the NEXT iteration + gru16's early share (update.py) may start from here
+            def ahead():
+                up32 = ub.run_gru32(pool, nets, inp_list)
+                return (up32, ub.gru16_early(pool, nets, inp_list, up32)) if "nog16split" not in _X else up32
+            at_join = None
+            if run_ahead and sp_join:
+                if streams_mod.MAIN_FIRST:
+                    at_join = mark()
+                else:
+                    early32 = spawn(ahead, site="gru32")           # rounds 2-3: enqueued before gru08 ("sidefirst,encmain,sp_join")
             sums = getattr(self, "_checksums", None)       # debugging hook (tools/determinism_check.py): device-side sums, no sync
             lazy = trace is None and sums is None           # the hooks want the flow head's / residual head's outputs as tensors
-            delta_flow = ub.run_fine(pool, nets, inp_list, m, up16, lazy=lazy, zr_early=zr_early, early_motion=g08m and zr_early is not None)
+            delta_flow = ub.run_fine(pool, nets, inp_list, m, up16, lazy=lazy)
+            if at_join is not None:
+                early32 = spawn(ahead, site="gru32", after=at_join)
             # disp_q = x - (coords1 + delta), 5 * disp2disp_gradient_xy (update.py:199) and the gradient candidates in one
             # launch (with the flow head's last convolution finished from its tap partials); coords1 is replaced by the blend
             # kernel's output below
@@ -355,9 +348,12 @@ class TCStereo(nn.Module):
                 disp_q, g5, cands = s16.flow_taps_step_grads(coords1, delta_flow, scale=5.0)
             else:
                 disp_q, g5, cands = ops.flow_step_grads(coords1, delta_flow, scale=5.0)
+            at_flow = mark() if (run_ahead and not sp_join) else None
             disp_grad, context = self.disp_grad_refine.run(pool, g5, cands, dg_pre, lazy=lazy, slot=itr if itr < IN_SUM_SLOTS else None)
             last = itr == iters - 1
             refined, up_mask, fused = self.disp_refine.run(pool, disp_grad, disp_q, nets[0], context, want_mask=last, motion=motion)
+            if run_ahead and not sp_join:
+                early32 = spawn(ahead, site="gru32", after=at_flow)     # enqueued last: never the first child of its fork point
             hu_delta = fused["delta_disp"]
             coords1, flows_x = fused["coords1"], fused["flow_x"]
             if sums is not None:

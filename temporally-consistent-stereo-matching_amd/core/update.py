@@ -112,9 +112,8 @@ def tap_partials(pool, conv1: nn.Conv2d, conv2: nn.Conv2d, srcs, pc=None, out16b
     ntile = (conv1.out_channels + 31) // 32
     taps = s16.Taps(pool.get32((id(conv2), "taps"), (a.B, ntile, 9 * conv2.out_channels, a.H, a.W), a.device), ntile, conv2.out_channels,
                     None if conv2.bias is None else conv2.bias.detach())
-    tc = 121812 if ("rpwfh" in _X and a.H * a.W >= 10000 and conv1.kernel_size[0] == 3) else 0
     s16.conv2d(packed16(conv1) if pc is None else pc, srcs, act="relu", taps=taps, tap_weights=tap_weights(conv2), out16b=out16b,
-               out16_split=conv1.out_channels if out16b is not None else 0, tile_cfg=tc)
+               out16_split=conv1.out_channels if out16b is not None else 0)
     return taps
 
 
@@ -139,20 +138,11 @@ def conv16(pool, conv, srcs, act="none", addend=None, post_scale=1.0, out=None, 
     pc = packed16(conv) if pc is None else pc
     stride = conv.stride[0]
     Ho, Wo = ((a.H - 1) // 2 + 1, (a.W - 1) // 2 + 1) if stride == 2 else (a.H, a.W)
-    tc = 0
-    if "t2" in _X and conv.kernel_size[0] == 3 and stride == 1 and a.H * a.W >= 10000:
-        tc = 101812                      # A/B: two-stage 8-row tiles on every 1/4-scale 3x3 layer
-    if "rpw" in _X and conv.kernel_size[0] == 3 and stride == 1 and a.H * a.W >= 10000 and conv.out_channels <= 128:
-        tc = 121812                      # A/B: two rows per wave on the 1/4-scale 3x3 layers with <= 128 outputs
-    if "norpw" in _X and conv.kernel_size[0] == 3 and stride == 1 and a.H * a.W >= 10000 and 96 <= conv.out_channels <= 128:
-        tc = 101411                      # A/B: round 2's tile where the heuristic now picks two rows per wave
     if want32:
-        return s16.conv2d(pc, srcs, act=act, addend=addend, post_scale=post_scale, want32=True, stride=stride, tile_cfg=tc,
-                          addend16=addend16)[1]
+        return s16.conv2d(pc, srcs, act=act, addend=addend, post_scale=post_scale, want32=True, stride=stride, addend16=addend16)[1]
     if out is None:
         out = pool.get((id(conv), tag), a.B, conv.out_channels, Ho, Wo, a.device)
-    return s16.conv2d(pc, srcs, act=act, addend=addend, post_scale=post_scale, out16=out, stride=stride, tile_cfg=tc,
-                      addend16=addend16)[0]
+    return s16.conv2d(pc, srcs, act=act, addend=addend, post_scale=post_scale, out16=out, stride=stride, addend16=addend16)[0]
 
 
 def conv32to16(pool, conv, x, act="none", tag="o", image_pair=None, in_transform=0):
@@ -285,14 +275,10 @@ class _GateCell(nn.Module):
         z = pool.get32((id(self), "z"), (h.B, h.C, h.H, h.W), h.device)
         rh = pool.get((id(self), "rh"), h.B, h.C, h.H, h.W, h.device)
         ctot = lambda t: 0 if (t is None or t.is_contiguous()) else int(t.stride(0)) // (h.H * h.W)
-        big = h.H * h.W >= 10000 and self.convzr.kernel_size[0] == 3
         if ctot(cz) != ctot(cr):
             cz, cr = cz.contiguous(), cr.contiguous()
-        s16.gru_gates(packed16(self.convzr), [h, *xs], h, cz, cr, z_out=z, rh_out=rh,
-                      tile_cfg=121812 if (big and "rpwzr" in _X) else (101411 if (big and "zr1411" in _X) else 0),
-                      addend_ctot=ctot(cz))
-        return s16.gru_update(packed16(self.convq), [rh, *xs], h, z, cq, keep_z=self.keep_z, out=h,
-                              tile_cfg=121812 if (big and "rpwq" in _X) else 0, addend_ctot=ctot(cq))
+        s16.gru_gates(packed16(self.convzr), [h, *xs], h, cz, cr, z_out=z, rh_out=rh, addend_ctot=ctot(cz))
+        return s16.gru_update(packed16(self.convq), [rh, *xs], h, z, cq, keep_z=self.keep_z, out=h, addend_ctot=ctot(cq))
 
 
 class ConvGRU(_GateCell):
@@ -529,50 +515,11 @@ class BasicMultiUpdateBlock(nn.Module):
                                        out=pool.get((id(self), "up16"), net[0].B, net[1].C, net[0].H, net[0].W, net[0].device))
         return None
 
-    # ---- gru08's gate convolution split the same way: net08 is final once the hidden-state update of the previous iteration has run,
-    # ~70 us before the motion features and interp(net16) arrive; its third of conv_zr's input channels (context addends and bias
-    # included) is contracted then, on a third parallel branch, and the launch on the critical chain is a K = 256 convolution ----
-    def gru08_early(self, pool, net, inp, motion=None):
-        """-> fp32 [B, 2*hidden, H, W] partial sums of gru08.convzr over the hidden-state channels (or, with `motion`, over the motion
-        features' channels) + cat(cz, cr) + bias, or None when the context tensors are not the three thirds of one tensor (then run_fine
-        contracts everything at once)."""
-        g, h = self.gru08, net[0]
-        hid = h.C
-        cz, cr, cq = inp[0]
-        plane = h.H * h.W
-        if not (cz.dtype == torch.float32 and cr.data_ptr() == cz.data_ptr() + hid * plane * 4 and cz.stride(0) == cr.stride(0) and
-                cz.stride(0) >= 2 * hid * plane and tuple(cz.stride()[1:]) == (plane, h.W, 1)):
-            return None
-        czr = torch.as_strided(cz, (h.B, 2 * hid, h.H, h.W), cz.stride())
-        p_zr = pool.get32((id(self), "p08zr"), (h.B, 2 * hid, h.H, h.W), h.device)
-        if motion is not None:
-            s16.conv2d(packed16_part(g.convzr, ((hid, hid + motion.C),)), [motion], addend=czr, addend_ctot=int(cz.stride(0)) // plane, out32=p_zr)
-        else:
-            s16.conv2d(packed16_part(g.convzr, ((0, hid),)), [h], addend=czr, addend_ctot=int(cz.stride(0)) // plane, out32=p_zr)
-        return p_zr
-
-    def run_fine(self, pool, net, inp, motion_features, up16, update=True, lazy=False, zr_early=None, early_motion=False):
+    def run_fine(self, pool, net, inp, motion_features, up16, update=True, lazy=False):
         """gru08 on (motion features, upsampled net16) and the flow head (update.py:154-168); returns delta_flow (fp32), or with
-        `lazy` the flow head's tap partials (FlowHead.run).  `zr_early`: gru08_early's partial sums of this iteration (`early_motion`:
-        taken over the motion features instead of the hidden state)."""
+        `lazy` the flow head's tap partials (FlowHead.run)."""
         xs = [motion_features] + ([up16] if up16 is not None else [])
-        if zr_early is None:
-            self.gru08.step16(pool, net[0], xs, *inp[0])
-        else:
-            g, h = self.gru08, net[0]
-            hid, cq = h.C, inp[0][2]
-            z = pool.get32((id(g), "z"), (h.B, hid, h.H, h.W), h.device)
-            rh = pool.get((id(g), "rh"), h.B, hid, h.H, h.W, h.device)
-            if early_motion:                        # the late share: hidden state + interp(net16)
-                m_c = motion_features.C
-                late = ((0, hid),) + (((hid + m_c, hid + m_c + up16.C),) if up16 is not None else ())
-                s16.gru_gates(packed16_part(g.convzr, late, with_bias=False), [h] + xs[1:], h, zr_early[:, :hid], zr_early[:, hid:], z_out=z,
-                              rh_out=rh, addend_ctot=2 * hid)
-            else:
-                s16.gru_gates(packed16_part(g.convzr, ((hid, hid + sum(x.C for x in xs)),), with_bias=False), xs, h, zr_early[:, :hid],
-                              zr_early[:, hid:], z_out=z, rh_out=rh, addend_ctot=2 * hid)
-            s16.gru_update(packed16(g.convq), [rh, *xs], h, z, cq, keep_z=g.keep_z, out=h,
-                           addend_ctot=0 if cq.is_contiguous() else int(cq.stride(0)) // (h.H * h.W))
+        self.gru08.step16(pool, net[0], xs, *inp[0])
         return self.flow_head.run(pool, net[0], lazy=lazy) if update else None
 
     def run(self, pool, net, inp, corr, flow, motion, iter08=True, iter16=True, iter32=True, update=True):
@@ -581,9 +528,9 @@ class BasicMultiUpdateBlock(nn.Module):
         if not iter08:
             self.run_coarse(pool, net, inp, iter16, iter32, want_up16=False)
             return None
-        # encoder on the origin stream (it forks again), coarse GRUs on a side stream
-        m, up16 = fork_join([lambda: self.encoder.run(pool, flow, corr, motion),
-                             lambda: self.run_coarse(pool, net, inp, iter16, iter32)], site="coarse")
+        # the coarse GRUs first (the longer chain stays in the launch list, streams.MAIN_FIRST), the motion encoder beside them
+        up16, m = fork_join([lambda: self.run_coarse(pool, net, inp, iter16, iter32),
+                             lambda: self.encoder.run(pool, flow, corr, motion)], site="coarse")
         return self.run_fine(pool, net, inp, m, up16, update)
 
 
@@ -622,27 +569,6 @@ class DispGradPredictor(nn.Module):
         grad, ctx = self.run(pool, g5, cands, self.prepare(pool, c16))
         return grad, ctx.float()
 
-    def _stems_block_diagonal(self):
-        """(34 -> 96 fp32-MFMA, 96 -> 96 fp16-split) packed convolutions = conv_grad_stem and conv_grad_candidate_stem side by side:
-        output channels 0-31 see only the gradient inputs / hidden channels, 32-95 only the candidates'."""
-        g0, g2, c0, c2 = self.conv_grad_stem[0], self.conv_grad_stem[2], self.conv_grad_candidate_stem[0], self.conv_grad_candidate_stem[2]
-        key = tuple((m.weight.data_ptr(), m.weight._version, m.bias.data_ptr(), m.bias._version) for m in (g0, g2, c0, c2))
-        hit = getattr(self, "_tcs_stems_bd", None)
-        if hit is None or hit[0] != key:
-            dev = g0.weight.device
-            ng, nc = g0.out_channels, c0.out_channels                       # 32, 64
-            w1 = torch.zeros(ng + nc, g0.in_channels + c0.in_channels, 3, 3, device=dev)
-            w1[:ng, :g0.in_channels] = g0.weight.detach()
-            w1[ng:, g0.in_channels:] = c0.weight.detach()
-            w2 = torch.zeros(g2.out_channels + c2.out_channels, ng + nc, 3, 3, device=dev)
-            w2[:g2.out_channels, :ng] = g2.weight.detach()
-            w2[g2.out_channels:, ng:] = c2.weight.detach()
-            b1 = torch.cat([g0.bias.detach(), c0.bias.detach()])
-            b2 = torch.cat([g2.bias.detach(), c2.bias.detach()])
-            hit = (key, (ops.pack_conv(w1, b1, "f32"), ops.pack_conv(w2, b2, "f16x3")))
-            self._tcs_stems_bd = hit
-        return hit[1]
-
     def prepare(self, pool, clist):
         """Once per frame.  conv_4_4 / conv_8_8 / conv_16_16 read cat(features, clist[i]) (update.py:205-209) and `clist` does
         not change over the iterations, so its share of each convolution (40 % / 40 % / 33 % of the input channels) is
@@ -677,21 +603,8 @@ class DispGradPredictor(nn.Module):
         def stem_c():
             return conv16(pool, self.conv_grad_candidate_stem[2], [conv32to16(pool, self.conv_grad_candidate_stem[0], cands, act="relu")])
 
-        if "stemsbd" in _X:
-            # OFF by default (A/B token "stemsbd"; measured +0.25 ms per frame against the forked stems, twice on one box).  The two stems
-            # (update.py:200-205) as ONE chain of two launches: their first layers read different tensors and their second layers
-            # different halves, so cat(grad stem, candidate stem) is a convolution with block-diagonal weights — 34 -> 96 on the
-            # fp32-MFMA kernel (the candidates are unbounded), then 96 -> 96 on S16.  The zero blocks add exact zeros; two launches and a
-            # fork / join leave the serial chain, but the two launches that remain are slower than the forked pairs they replace.
-            pc1, pc2 = self._stems_block_diagonal()
-            a1 = pool.get((id(self), "stems1"), g5.shape[0], 96, g5.shape[2], g5.shape[3], g5.device)
-            ops.conv2d(pc1, [g5, cands], act="relu", out16=a1)
-            x4_stems = pool.get((id(self), "stems2"), g5.shape[0], 96, g5.shape[2], g5.shape[3], g5.device)
-            s16.conv2d(pc2, [a1], out16=x4_stems)
-            x4 = feat(self.conv_4_4[0], [x4_stems], pre[0])
-        else:
-            x4_cand, x4_grad = fork_join([stem_c, stem_g], site="stems")   # the longer chain (fp32-MFMA candidate stem) on the origin stream
-            x4 = feat(self.conv_4_4[0], [x4_grad, x4_cand], pre[0])
+        x4_cand, x4_grad = fork_join([stem_c, stem_g], site="stems")       # the longer chain (fp32-MFMA candidate stem) first
+        x4 = feat(self.conv_4_4[0], [x4_grad, x4_cand], pre[0])
         x8 = conv16(pool, self.conv_4_8[0], [x4], act="relu")                    # 3x3 stride 2
         x8 = feat(self.conv_8_8[0], [x8], pre[1])
         x16 = conv16(pool, self.conv_8_16[0], [x8], act="relu")                  # 3x3 stride 2
@@ -753,23 +666,22 @@ class DispRefine(nn.Module):
             motion: s16.S16 = None):
         """-> (refined fp32, mask fp32 or None, dict(delta_disp, coords1, flow_x)).  With `motion`, the next iteration's flow input
         (coords1 - x) also lands in channel 127 of that S16 buffer (tc_stereo.py:180, update.py:126)."""
+        # the candidate stencil (with the residual head's last convolution finished from its tap partials) stays on the chain; behind it
+        # the context branch (the longer one) continues the chain and the two 1x1 layers of the candidate stem run beside it
+        f27 = pool.get((id(self), "f27"), disp.shape[0], 27, disp.shape[2], disp.shape[3], disp.device)
+        if isinstance(disp_grads, tuple):        # (tap partials of residual_head[2], 5*grad, 1/5) from DispGradPredictor.run(lazy=True)
+            f27, cand9, self._last_grad = s16.taps_propagate(disp_grads[0], disp_grads[1], disp_grads[2], disp, out16=f27)
+        else:
+            f27, cand9 = s16.propagate_disparity(disp_grads, disp, out16=f27)
+
         def cand_branch():
-            f27 = pool.get((id(self), "f27"), disp.shape[0], 27, disp.shape[2], disp.shape[3], disp.device)
-            if isinstance(disp_grads, tuple):        # (tap partials of residual_head[2], 5*grad, 1/5) from DispGradPredictor.run(lazy=True)
-                f27, cand9, self._last_grad = s16.taps_propagate(disp_grads[0], disp_grads[1], disp_grads[2], disp, out16=f27)
-            else:
-                f27, cand9 = s16.propagate_disparity(disp_grads, disp, out16=f27)
-            d = conv16(pool, self.disp_f_stem[0], [f27], act="relu")
-            return cand9, conv16(pool, self.disp_f_stem[2], [d])
+            return conv16(pool, self.disp_f_stem[2], [conv16(pool, self.disp_f_stem[0], [f27], act="relu")])
 
         def ctx_branch():
             c = conv16(pool, self.context_compress[0], [context_disp, context_grad], act="relu")
             return conv16(pool, self.context_compress[2], [c])
 
-        if "swaprefine" in _X:
-            (cand9, disp_f), context = fork_join([cand_branch, ctx_branch], site="refine")
-        else:
-            context, (cand9, disp_f) = fork_join([ctx_branch, cand_branch], site="refine")
+        context, disp_f = fork_join([ctx_branch, cand_branch], site="refine")
         fused = conv16(pool, self.conv_fuse[0], [disp_f, context], act="relu")
         fused = conv16(pool, self.conv_fuse[2], [fused], act="relu")
         w = conv16(pool, self.w_head[0], [fused], act="relu")

@@ -5,9 +5,11 @@ A frame has two parts.  EXTRACT — image normalisation, feature / context netwo
 arg-max prior, disparity completion, hidden-state warp and the refinement loop (tc_stereo.py:119-229) — needs EXTRACT's
 features and the previous frame's outputs.  Frames of a sequence are serial through REFINE only, so the EXTRACT of frame t+1
 can run while the REFINE of frame t still does: `prefetch(image1, image2)` launches it on a second stream into the free one
-of two feature slots, and the following `__call__` with the same image tensors finds it there.  The refinement loop leaves
-about half of the GPU idle at one 640x480 sequence (150-600 workgroup launches on 256 CUs), which is where the ~2 ms of
-feature extraction go.  Without a prefetch the two stages simply run back to back, as the reference does.
+of two feature slots, and the following `__call__` with the same image tensors finds it there.  What that buys, as measured
+(profiles/r03_frame_phases.txt): the HOST-side launch work of the next EXTRACT (0.35-0.6 ms per frame) leaves
+the frame's serial path; on the GPU the extraction does NOT run beside the loop (its first kernel starts 0.4-1.3 ms after the
+frame's last one — the loop's graph occupies the hardware queues).  Without a prefetch the two stages simply run back to back, as
+the reference does.
 
 Each stage is ~100 / ~1,700 kernel launches with static shapes and no host decision inside, so it is captured once per
 (shape, branch[, iteration count]) and slot into a HIP graph and replayed.  Inputs are copied into the graph's static
@@ -26,9 +28,7 @@ from typing import Callable, Dict, List, Optional
 
 import torch
 
-# A/B switch (TCS_MI355_X token, never set in production): "xlow" = the extract stream at low priority.  (Replaying the refine stage on a
-# high-priority stream instead doubled the frame time on ROCm 7.2: 28 -> 58 ms; removed.)
-_X = set(t for t in os.environ.get("TCS_MI355_X", "").split(",") if t)
+_CAPTURING = 0          # > 0 while any FrameGraphs capture is recording (FrameGraphs.drop refuses then)
 
 
 def _flatten(temporal):
@@ -70,10 +70,14 @@ class _no_gc:
     the previous captures)."""
 
     def __enter__(self):
+        global _CAPTURING
         self.was = gc.isenabled()
         gc.disable()
+        _CAPTURING += 1
 
     def __exit__(self, *exc):
+        global _CAPTURING
+        _CAPTURING -= 1
         if self.was:
             gc.enable()
         return False
@@ -87,6 +91,7 @@ class _Slot:
         self.token = None                      # identifies the images (and mode) the features belong to
         self.fresh = False                     # features nobody has consumed yet
         self.by_prefetch = False
+        self.age = 0                           # calls since the features were produced without anybody consuming them
         self.ex_key = None
         self.ready = torch.cuda.Event()        # EXTRACT done (recorded on the extract stream)
         self.free = torch.cuda.Event()         # the REFINE that read the features is done (recorded on the caller's stream)
@@ -139,15 +144,31 @@ class FrameGraphs:
                 self.turn, self.epoch = 0, now
                 gc.collect()                   # the dropped captures die here, not inside the next capture (see _no_gc)
 
+    def drop(self):
+        """Release every captured graph NOW (e.g. between two benchmark legs).  Destroying a HIP graph while another stream is recording a
+        capture aborts the process on ROCm 7.2 (the round-3 abort came through the garbage collector; `del` / `= None` of a FrameGraphs
+        or of its entries is the same thing by hand), so this refuses while any capture is active, waits for the device, drops the
+        entries and collects at once."""
+        if _CAPTURING:
+            raise RuntimeError("FrameGraphs.drop() while a HIP graph capture is recording")
+        torch.cuda.synchronize()
+        self.ex.clear()
+        self.rf.clear()
+        self.slots = [_Slot(), _Slot()]
+        self.turn = 0
+        gc.collect()
+
     def _stream(self, device) -> torch.cuda.Stream:
         st = self._sx.get(device)
         if st is None:
-            st = self._sx[device] = torch.cuda.Stream(device=device, priority=1 if "xlow" in _X else 0)
+            st = self._sx[device] = torch.cuda.Stream(device=device)
         return st
 
     def _pick_slot(self) -> int:
         """Where the next EXTRACT goes: the slot whose features have been consumed (a prefetch made for the NEXT frame must survive
-        the call for the current one); with two unconsumed sets, the older."""
+        the call for the current one); with two unconsumed sets, the older.  A prefetch nobody consumed ages out (`__call__`): after
+        two calls that did not match it the slot is free again and its image tensors are released — one mispredicted prefetch must not
+        pin a slot (and with it the two-executable alternation) for the rest of the process."""
         for k in (self.turn, self.turn ^ 1):
             if not self.slots[k].fresh:
                 return k
@@ -176,9 +197,14 @@ class FrameGraphs:
     def _capture_extract(self, key, image1, image2, first) -> Optional[List[_Entry]]:
         static_in = [image1.clone(), image2.clone()]
         run = lambda: self.extract_fn(static_in[0], static_in[1], first)
+        # The warm-up and the capture write the model's pool buffers, which every extract key of this shape shares: an EXTRACT still in
+        # flight on the extract stream (a prefetch) must be over first, and whatever a slot holds unconsumed is no longer trustworthy.
+        for sl in self.slots:
+            sl.fresh, sl.token = False, None
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
+            side.wait_stream(self._stream(image1.device))
             with torch.cuda.stream(side):
                 for _ in range(self.warmup):        # packs weights, sizes the pools
                     run()
@@ -232,7 +258,7 @@ class FrameGraphs:
                 for t in _tensors(slot.feats):       # allocated on the extract stream, read on the caller's: keep the blocks alive for it
                     t.record_stream(main)
             slot.ready.record(sx)
-        slot.token, slot.ex_key, slot.fresh, slot.by_prefetch = self._token(image1, image2, first, use_graph), key, True, False
+        slot.token, slot.ex_key, slot.fresh, slot.by_prefetch, slot.age = self._token(image1, image2, first, use_graph), key, True, False, 0
         self.turn = si ^ 1
 
     def prefetch(self, image1, image2, first: bool = False, use_graph: bool = True, inputs_ready: bool = False) -> int:
@@ -307,6 +333,12 @@ class FrameGraphs:
             if entries is None:
                 self.fell_back += 1
         si = next((k for k in (0, 1) if self.slots[k].fresh and self._same(self.slots[k].token, token)), None)
+        for k in (0, 1):                                # unconsumed features this call does not match: one call older
+            sl = self.slots[k]
+            if sl.fresh and k != si:
+                sl.age += 1
+                if sl.age >= 2:
+                    sl.fresh, sl.token = False, None
         if si is not None:
             self.prefetched += int(self.slots[si].by_prefetch)
         else:

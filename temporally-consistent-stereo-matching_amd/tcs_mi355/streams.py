@@ -21,6 +21,14 @@ import torch
 ENABLED = os.environ.get("TCS_MI355_STREAMS", "1") == "1"
 SITES = os.environ.get("TCS_MI355_FORK_SITES", "all").split(",")       # diagnostic: restrict forking to named call sites
 OFF = set(t for t in os.environ.get("TCS_MI355_FORK_OFF", "").split(",") if t)      # diagnostic (A/B runs): call sites that run serially
+# Capture order at a fork.  ROCm's graph executor cuts a captured graph into launch lists by a depth-first walk that follows a node's
+# FIRST captured child: that child stays in its parent's list (same hardware queue, ~1.5 us boundary), every later child starts a
+# new list whose first node waits for the parent across queues (~10 us) and whose last node the join waits for across queues
+# again.  MAIN_FIRST (default): the branch given first to fork_join — by convention the one on the iteration's critical chain —
+# is enqueued BEFORE the side branches (which wait for an event recorded at the fork point), so the critical chain never
+# leaves its queue and the side branches, which have slack, absorb the cross-queue latencies.  "sidefirst" in TCS_MI355_X restores
+# the round-2/3 order (side branches first) for A/B runs.
+MAIN_FIRST = "sidefirst" not in set(os.environ.get("TCS_MI355_X", "").split(","))
 _POOL: dict = {}
 _DEPTH = 0          # nesting level of fork_join: each level owns its own side streams (a nested fork must never
                     # pick the stream it is already running on)
@@ -64,10 +72,21 @@ class Spawned:
         self.result, self.stream = result, stream
 
 
-def spawn(fn: Callable[[], object], site: str = "", slot: int = 0) -> Spawned:
+def mark():
+    """An event at the current point of the current stream (a fork point for `spawn(..., after=)`); None when forking is off."""
+    if not ENABLED or _IN_SIDE > 0 or not torch.cuda.is_available():
+        return None
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    return ev
+
+
+def spawn(fn: Callable[[], object], site: str = "", slot: int = 0, after=None) -> Spawned:
     """Enqueue `fn` on a side stream behind everything already on the current stream and return at once; `join` makes the
     current stream wait for it.  Used for work whose result is needed much later (the next iteration's gru32).  Spawns that
-    are in flight at the same time take different `slot`s (one stream each)."""
+    are in flight at the same time take different `slot`s (one stream each).  `after` (a `mark()`): the side chain starts
+    behind THAT point of the current stream instead — work enqueued on the current stream since then neither delays it nor, under
+    capture, loses its place as the first child of the fork point (see MAIN_FIRST)."""
     global _IN_SIDE, _DEPTH
     if not ENABLED or _IN_SIDE > 0 or not torch.cuda.is_available() or ("all" not in SITES and site not in SITES) or site in OFF:
         return Spawned(fn(), None)
@@ -76,7 +95,10 @@ def spawn(fn: Callable[[], object], site: str = "", slot: int = 0) -> Spawned:
     while len(pool) <= slot:
         pool.append(torch.cuda.Stream(device=cur.device))
     st = pool[slot]
-    st.wait_stream(cur)
+    if after is not None:
+        st.wait_event(after)
+    else:
+        st.wait_stream(cur)
     _IN_SIDE += 1
     try:
         with torch.cuda.stream(st):
@@ -109,15 +131,23 @@ def fork_join(fns: Sequence[Callable[[], object]], site: str = "") -> list:
     results = [None] * len(fns)
     _DEPTH += 1
     try:
+        if MAIN_FIRST:
+            here = torch.cuda.Event()
+            here.record(cur)
+            results[0] = fns[0]()
         for i, st in enumerate(sides, start=1):
-            st.wait_stream(cur)
+            if MAIN_FIRST:
+                st.wait_event(here)
+            else:
+                st.wait_stream(cur)
             _IN_SIDE += 1
             try:
                 with torch.cuda.stream(st):
                     results[i] = fns[i]()
             finally:
                 _IN_SIDE -= 1
-        results[0] = fns[0]()
+        if not MAIN_FIRST:
+            results[0] = fns[0]()
     finally:
         _DEPTH -= 1
     for st in sides:

@@ -318,30 +318,6 @@ def test_cells_and_blocks_golden(dev, ops_golden, model):
         assert maxdiff(nets[i], g[f"dc_out{i}"]) <= 2e-4
 
 
-def test_gru08_gate_split_equals_one_launch(dev, ops_golden, model):
-    """BasicMultiUpdateBlock.gru08_early + run_fine(zr_early=...) (the A/B tokens g08split / g08m of the frame loop) against the one-launch
-    gate convolution on the golden block inputs: the same products in another summation order."""
-    from core.update import pool_of
-    from tcs_mi355 import s16
-    g = ops_golden
-    ub, pool = model.update_block, pool_of(model)
-    h0 = D(g["ub_h08"], dev)
-    zqr = torch.cat([D(g[f"ub_ctx0{n}"], dev) for n in "zrq"], 1).contiguous()        # (cz | cr | cq) as thirds of one tensor, as the context network leaves them
-    hid = h0.shape[1]
-    inp0 = [zqr[:, i * hid:(i + 1) * hid] for i in range(3)]
-    gen = torch.Generator().manual_seed(5)
-    m = s16.to_s16(D(torch.randn(h0.shape[0], 128, h0.shape[2], h0.shape[3], generator=gen), dev))
-    up16 = s16.to_s16(D(torch.randn(h0.shape[0], ub.gru16.convq.out_channels, h0.shape[2], h0.shape[3], generator=gen), dev))
-    outs = []
-    for split in ("", "h", "m"):                 # one launch / early share over the hidden state (g08split) / over the motion features (g08m)
-        nets = [s16.to_s16(h0.clone())]
-        early = ub.gru08_early(pool, nets, [inp0], motion=m if split == "m" else None) if split else None
-        assert (early is not None) == bool(split)
-        ub.run_fine(pool, nets, [inp0], m, up16, update=False, zr_early=early, early_motion=split == "m")
-        outs.append(nets[0].float().clone())
-    assert maxdiff(outs[1], outs[0]) <= 2e-5 and maxdiff(outs[2], outs[0]) <= 2e-5
-
-
 # ------------------------------------------------------------------------------------------------
 # end to end
 # ------------------------------------------------------------------------------------------------

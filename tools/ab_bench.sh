@@ -10,7 +10,7 @@ for r in $(seq 1 $rounds); do
     [[ "$v" == *@* ]] && args=${v#*@}
     [[ "$x" == --* ]] && { args="$x $args"; x=""; }
     [ "$x" = "-" ] && x=""
-    ms=$(TCS_MI355_X=$x python bench.py --steps 20 --warmup 3 --no-cpu-baseline --batched-leg 0 $args 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], 'per-step min/median/max', d['step_ms_min_median_max'])")
+    ms=$(TCS_MI355_X=$x python bench.py --steps 20 --warmup 3 --quick $args 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], 'per-step min/median/max', d['step_ms_min_median_max'])")
     echo "round $r variant [$v] ms_per_step $ms"
   done
 done

@@ -3,7 +3,7 @@
 # usage: tools/ab_sites.sh <rounds> <site> [<site> ...]
 ALL="frame,iter,enc,gru32,stems,heads,refine,coarse"
 rounds=$1; shift
-run() { TCS_MI355_FORK_SITES=$1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --batched-leg 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], d['step_ms_min_median_max'])"; }
+run() { TCS_MI355_FORK_SITES=$1 python bench.py --steps 10 --warmup 3 --quick 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], d['step_ms_min_median_max'])"; }
 for r in $(seq 1 $rounds); do
   echo "round $r all: $(run all)"
   for s in "$@"; do

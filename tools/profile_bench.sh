@@ -7,7 +7,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$1; shift
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 $root/bench.py --steps 8 --warmup 3 --no-cpu-baseline --batched-leg 0 "$@" \
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -- python3 $root/bench.py --steps 8 --warmup 3 --no-cpu-baseline --batched-leg 0 --drop-in-steps 0 --kitti-steps 0 "$@" \
     > $out/bench_prof.json 2> $out/bench_prof.err
 cd $root
 trace=$(find $out/prof -name "*kernel_trace.csv" | head -1)

@@ -5,13 +5,13 @@
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$1
 mkdir -p $out
-common="--warmup 3 --no-cpu-baseline --batched-leg 0"
+common="--warmup 3 --no-cpu-baseline --batched-leg 0 --drop-in-steps 0 --kitti-steps 0"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $out/p1 -- python3 $root/bench.py --steps 8 $common > $out/bench_1seq.json 2> $out/bench_1seq.err
 rocprofv3 --kernel-trace --output-format csv -d $out/p4 -- python3 $root/bench.py --steps 4 --seqs-per-gpu 4 $common > $out/bench_4seq.json 2> $out/bench_4seq.err
 rocprofv3 --kernel-trace --output-format csv -d $out/pk -- python3 $root/bench.py --steps 6 --size 375x1242 $common > $out/bench_kitti.json 2> $out/bench_kitti.err
-rocprofv3 --pmc FETCH_SIZE --kernel-include-regex k_corr_lookup --output-format csv -d $out/fetch -- python3 $root/bench.py --steps 2 --warmup 2 --no-cpu-baseline --batched-leg 0 --eager > /dev/null 2> $out/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-include-regex k_corr_lookup --output-format csv -d $out/write -- python3 $root/bench.py --steps 2 --warmup 2 --no-cpu-baseline --batched-leg 0 --eager > /dev/null 2> $out/pmc_write.err
+rocprofv3 --pmc FETCH_SIZE --kernel-include-regex k_corr_lookup --output-format csv -d $out/fetch -- python3 $root/bench.py --steps 2 --warmup 2 --no-cpu-baseline --batched-leg 0 --drop-in-steps 0 --kitti-steps 0 --eager > /dev/null 2> $out/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-include-regex k_corr_lookup --output-format csv -d $out/write -- python3 $root/bench.py --steps 2 --warmup 2 --no-cpu-baseline --batched-leg 0 --drop-in-steps 0 --kitti-steps 0 --eager > /dev/null 2> $out/pmc_write.err
 cd $root
 for p in p1 p4 pk; do
   trace=$(find $out/$p -name "*kernel_trace.csv" | head -1)
