@@ -277,6 +277,10 @@ int tcs_conv3x3_cout1(const float* x, const float* w_oihw, const float* bias, in
 /* nn.Conv2d(k, padding=k/2) + fused epilogue; covers ConvGRU / Lightfuse / HiddenstateUpdater /
  * BasicMotionEncoder / FlowHead / the stride-1 convs of DispRefine and DispGradPredictor (core/update.py). */
 int tcs_conv2d(const tcs_conv_desc* desc, tcs_stream_t stream);
+/* n (1 or 2) INDEPENDENT convolutions of tcs_conv2d as one launch where a grouped kernel exists for them (two fp32-MFMA 3x3 layers of
+ * <= 32-channel tiles: the first layers of DispGradPredictor's stems, core/update.py:200-205), otherwise one after the other; bit-equal
+ * to n calls of tcs_conv2d either way (see tcs_conv2d_s16_group). */
+int tcs_conv2d_group(const tcs_conv_desc* const* descs, int n, tcs_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------------
  * Pre-split activations ("S16" tensors): the refinement loop's internal activation format.
@@ -436,6 +440,15 @@ int tcs_hidden_update_s16(void* h, int h_groups, const float* delta, const float
 
 /* nn.Conv2d / ConvGRU step on S16 activations (core/update.py:16-17,26-36,57-68,77-87,103-111,198-214,291-305) */
 int tcs_conv2d_s16(const tcs_conv_s16_desc* desc, tcs_stream_t stream);
+
+/* n (1 or 2) INDEPENDENT convolutions of tcs_conv2d_s16 — no output of one is an input of another; same batch size — issued as ONE
+ * launch where a grouped kernel exists for their tile instances (the pairs of the refinement loop: BasicMotionEncoder.convc2 | convf2
+ * core/update.py:105-108, the second layers of DispGradPredictor's stems :200-205, DispRefine.context_compress | disp_f_stem :293-297),
+ * otherwise one after the other.  Results are bit-equal to n calls of tcs_conv2d_s16 in either case; what the grouped launch saves is the
+ * cross-queue dependency a fork / join of two graph branches costs.  tcs_conv2d_s16_group_fused: 1 when the two
+ * descriptors would run as one launch (no launch is made). */
+int tcs_conv2d_s16_group(const tcs_conv_s16_desc* const* descs, int n, tcs_stream_t stream);
+int tcs_conv2d_s16_group_fused(const tcs_conv_s16_desc* const* descs, int n);
 
 #ifdef __cplusplus
 }

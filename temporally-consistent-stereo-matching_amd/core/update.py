@@ -129,6 +129,9 @@ def pool_of(module) -> s16.S16Pool:
 
 # A/B switches for benchmarking sessions (tools/, gpurun logs): comma-separated tokens in TCS_MI355_X.  Never set in production.
 _X = set(t for t in os.environ.get("TCS_MI355_X", "").split(",") if t)
+# Independent layer pairs as ONE grouped launch (tcs_conv2d_s16_group / tcs_conv2d_group) instead of two branches of the captured graph;
+# "nogroup" (A/B): the round-3 forks (stems, refine) resp. two launches in a row (encoder).
+GROUP = "nogroup" not in _X
 
 
 def conv16(pool, conv, srcs, act="none", addend=None, post_scale=1.0, out=None, want32=False, tag="o", addend16=None, pc=None):
@@ -390,13 +393,12 @@ class BasicMotionEncoder(nn.Module):
     def run(self, pool, flow: torch.Tensor, corr: torch.Tensor, motion: s16.S16) -> s16.S16:
         """`motion`: the S16 [N,128,H,W] motion feature buffer whose channel 127 ALREADY holds `flow`; channels 0..126 are
         written here (the 127-channel epilogue never touches channel 127: masked partial store)."""
-        def cor():
-            return conv16(pool, self.convc2, [conv32to16(pool, self.convc1, corr, act="relu")], act="relu")
-
-        def flo():
-            return conv16(pool, self.convf2, [conv32to16(pool, self.convf1, flow, act="relu")], act="relu")
-
-        c, f = fork_join([cor, flo], site="enc")
+        # convc2 | convf2 (two independent 3x3 64 -> 64 layers) as ONE grouped launch (tcs_conv2d_s16_group) instead of two graph branches
+        c1 = conv32to16(pool, self.convc1, corr, act="relu")
+        f1 = conv32to16(pool, self.convf1, flow, act="relu")
+        with s16.grouped(enabled=GROUP):
+            c = conv16(pool, self.convc2, [c1], act="relu")
+            f = conv16(pool, self.convf2, [f1], act="relu")
         return conv16(pool, self.conv, [c, f], act="relu", out=motion)
 
 
@@ -545,6 +547,8 @@ class DispGradPredictor(nn.Module):
         self.conv_grad_candidate_stem = _two(32, 64, 64)
         # its input (-n_x/n_z of neighbour cross products, geo_utils.py:99-100) is unbounded: keep fp32 operands
         self.conv_grad_candidate_stem[0]._tcs_math = "f32"
+        # (2 -> 32: K = 18.  On the fp32-MFMA kernel too, so that it can share a grouped launch with the candidate stem's first layer)
+        self.conv_grad_stem[0]._tcs_math = "f32"
         relu = lambda: nn.ReLU(inplace=True)
         self.conv_4_4 = nn.Sequential(_conv(160, 64, 3), relu())
         self.conv_4_8 = nn.Sequential(_conv(64, 96, 3, 2), relu())
@@ -597,13 +601,19 @@ class DispGradPredictor(nn.Module):
             n = sum(t.C for t in srcs)
             return conv16(pool, conv, srcs, act="relu", addend=share, pc=packed16_part(conv, ((0, n),), with_bias=False))
 
-        def stem_g():
-            return conv16(pool, self.conv_grad_stem[2], [conv32to16(pool, self.conv_grad_stem[0], g5, act="relu")])
-
-        def stem_c():
-            return conv16(pool, self.conv_grad_candidate_stem[2], [conv32to16(pool, self.conv_grad_candidate_stem[0], cands, act="relu")])
-
-        x4_cand, x4_grad = fork_join([stem_c, stem_g], site="stems")       # the longer chain (fp32-MFMA candidate stem) first
+        gs, cs = self.conv_grad_stem, self.conv_grad_candidate_stem
+        if GROUP:
+            # the two stems (update.py:200-205) layer by layer as grouped launches: [2 -> 32 | 32 -> 64] on the fp32-MFMA kernel (the
+            # candidates are unbounded; the gradient stem rides the same instance), then [32 -> 32 | 64 -> 64] on S16 — no fork, no join
+            with ops.grouped():
+                g1 = conv32to16(pool, gs[0], g5, act="relu")
+                c1 = conv32to16(pool, cs[0], cands, act="relu")
+            with s16.grouped():
+                x4_grad = conv16(pool, gs[2], [g1])
+                x4_cand = conv16(pool, cs[2], [c1])
+        else:
+            x4_cand, x4_grad = fork_join([lambda: conv16(pool, cs[2], [conv32to16(pool, cs[0], cands, act="relu")]),
+                                          lambda: conv16(pool, gs[2], [conv32to16(pool, gs[0], g5, act="relu")])], site="stems")
         x4 = feat(self.conv_4_4[0], [x4_grad, x4_cand], pre[0])
         x8 = conv16(pool, self.conv_4_8[0], [x4], act="relu")                    # 3x3 stride 2
         x8 = feat(self.conv_8_8[0], [x8], pre[1])
@@ -674,14 +684,18 @@ class DispRefine(nn.Module):
         else:
             f27, cand9 = s16.propagate_disparity(disp_grads, disp, out16=f27)
 
-        def cand_branch():
-            return conv16(pool, self.disp_f_stem[2], [conv16(pool, self.disp_f_stem[0], [f27], act="relu")])
-
-        def ctx_branch():
-            c = conv16(pool, self.context_compress[0], [context_disp, context_grad], act="relu")
-            return conv16(pool, self.context_compress[2], [c])
-
-        context, disp_f = fork_join([ctx_branch, cand_branch], site="refine")
+        cc, ds = self.context_compress, self.disp_f_stem
+        if GROUP:
+            # context_compress (3x3, 192 -> 96 -> 96) beside disp_f_stem (1x1, 27 -> 96 -> 96), layer by layer as grouped launches
+            with s16.grouped():
+                c = conv16(pool, cc[0], [context_disp, context_grad], act="relu")
+                d = conv16(pool, ds[0], [f27], act="relu")
+            with s16.grouped():
+                context = conv16(pool, cc[2], [c])
+                disp_f = conv16(pool, ds[2], [d])
+        else:
+            context, disp_f = fork_join([lambda: conv16(pool, cc[2], [conv16(pool, cc[0], [context_disp, context_grad], act="relu")]),
+                                         lambda: conv16(pool, ds[2], [conv16(pool, ds[0], [f27], act="relu")])], site="refine")
         fused = conv16(pool, self.conv_fuse[0], [disp_f, context], act="relu")
         fused = conv16(pool, self.conv_fuse[2], [fused], act="relu")
         w = conv16(pool, self.w_head[0], [fused], act="relu")

@@ -22,7 +22,7 @@
 extern "C" size_t tcs_conv_packed_floats_f16x3(int Cout, int Cin, int ksize);
 
 template <int KS, int MT, int KC, int EPI>
-__global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a) {
+__device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, const int bid, const int b) {
     constexpr int NT = 32 * MT, HALO = KS / 2, IH = 4 + KS - 1, IW = 32 + KS - 1, TAPS = KS * KS;
     constexpr int IN_CH = IH * IW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -31,9 +31,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bid = blockIdx.x;
     const int ct = bid % a.nct, patch = bid / a.nct;
-    const int b = blockIdx.y;
     const int y0 = (patch / a.npx) * 4, x0 = (patch % a.npx) * 32;
     const int H = a.H, W = a.W;
     const size_t HW = (size_t)H * W;
@@ -127,6 +125,21 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a) {
     const size_t pix = (size_t)py * W + px;
 #pragma unroll
     for (int m = 0; m < MT; ++m) conv_epilogue_tile<EPI>(a, b, ct * NT + m * 32 + 4 * half, pix, HW, acc[m], 1.0f);
+}
+
+template <int KS, int MT, int KC, int EPI>
+__global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a) {
+    conv_mfma_body<KS, MT, KC, EPI>(a, blockIdx.x, blockIdx.y);
+}
+
+// Two independent convolutions of the same tile instance as ONE launch: blocks [0, n0) are problem 0's, the rest problem 1's
+// (the first layers of the gradient predictor's two stems, core/update.py:200-205 — see k_conv_s16_pair in tcs_conv_s16.hip for
+// what a grouped launch saves).  Bit-equal to the two separate launches.
+template <int KS, int MT, int KC, int EPI>
+__global__ __launch_bounds__(256) void k_conv_mfma_pair(ConvArgs a0, ConvArgs a1, int n0) {
+    const int bid = blockIdx.x;
+    if (bid < n0) conv_mfma_body<KS, MT, KC, EPI>(a0, bid, blockIdx.y);
+    else conv_mfma_body<KS, MT, KC, EPI>(a1, bid - n0, blockIdx.y);
 }
 
 // epilogue of the single-input-channel kernels: 16 output channels co_lo .. co_lo+15 of one pixel -> fp32 NCHW and/or S16
@@ -288,11 +301,27 @@ __global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ w
     packed[i] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * taps + t] : 0.f;
 }
 
+// a launch that tcs_conv2d_group has asked to be planned instead of issued (tcs_conv_s16.hip: S16Plan)
+struct ConvPlan {
+    bool filled;
+    int key;                        // KS * 10000 + MT * 1000 + KC * 10 + EPI
+    ConvArgs args;
+    int (*launch_alone)(const ConvArgs&, hipStream_t);
+};
+static thread_local ConvPlan* g_conv_plan = nullptr;
+
 template <int KS, int MT, int KC, int EPI>
 static int launch_mfma(const ConvArgs& a, hipStream_t s) {
     constexpr int IH = 4 + KS - 1, IW = 32 + KS - 1, TAPS = KS * KS, NT = 32 * MT;
     const size_t lds = ((size_t)((KC * IH * IW + 3) & ~3) + (size_t)KC * TAPS * NT) * sizeof(float);
     auto kern = k_conv_mfma<KS, MT, KC, EPI>;
+    if (g_conv_plan && !g_conv_plan->filled) {
+        g_conv_plan->filled = true;
+        g_conv_plan->key = KS * 10000 + MT * 1000 + KC * 10 + EPI;
+        g_conv_plan->args = a;
+        g_conv_plan->launch_alone = &launch_mfma<KS, MT, KC, EPI>;
+        return TCS_OK;
+    }
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return TCS_ELAUNCH;
@@ -434,6 +463,34 @@ int tcs_conv2d(const tcs_conv_desc* d, tcs_stream_t stream) {
         return TCS_EUNSUPPORTED;
     }
     return TCS_EINVAL;
+}
+
+int tcs_conv2d_group(const tcs_conv_desc* const* descs, int n, tcs_stream_t stream) {
+    if (!descs || n < 1 || n > 2) return TCS_EINVAL;
+    if (n == 1) return tcs_conv2d(descs[0], stream);
+    ConvPlan plan[2];
+    for (int i = 0; i < 2; ++i) {
+        plan[i].filled = false;
+        g_conv_plan = &plan[i];
+        const int rc = tcs_conv2d(descs[i], stream);      // kernels without a planner (fp16-split, 7x7, single-channel) launch right here
+        g_conv_plan = nullptr;
+        if (rc != TCS_OK) return rc;
+    }
+    hipStream_t s = tcs_stream(stream);
+    constexpr int key = 3 * 10000 + 1 * 1000 + 16 * 10 + TCS_EPI_LINEAR;
+    if (plan[0].filled && plan[1].filled && plan[0].key == key && plan[1].key == key && plan[0].args.B == plan[1].args.B) {
+        constexpr size_t lds = ((size_t)((16 * 6 * 34 + 3) & ~3) + (size_t)16 * 9 * 32) * sizeof(float);
+        const int n0 = plan[0].args.npatch * plan[0].args.nct, n1 = plan[1].args.npatch * plan[1].args.nct;
+        hipLaunchKernelGGL((k_conv_mfma_pair<3, 1, 16, TCS_EPI_LINEAR>), dim3(n0 + n1, plan[0].args.B), dim3(256), lds, s, plan[0].args,
+                           plan[1].args, n0);
+        return tcs_launch_status();
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (!plan[i].filled) continue;                     // (already issued)
+        const int r = plan[i].launch_alone(plan[i].args, s);
+        if (r != TCS_OK) return r;
+    }
+    return TCS_OK;
 }
 
 }  // extern "C"

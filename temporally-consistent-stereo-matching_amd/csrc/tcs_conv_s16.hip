@@ -454,8 +454,10 @@ constexpr int s16_min_waves(int MT, int EPI, int RPW, bool TP) {
     return 1;
 }
 
+// The kernel body as a device function of (arguments, block index, blocks of this problem, batch element): k_conv_s16 runs one
+// problem per launch, k_conv_s16_pair two independent problems in ONE launch (block-index ranges), see below.
 template <int KS, int MT, int ROWS, int KSTEPS, int NSTAGE, int STRIDE, int EPI, int RS = 0, int RPW = 1, bool TP = false>
-__global__ __launch_bounds__(64 * ROWS / RPW, s16_min_waves(MT, EPI, RPW, TP)) void k_conv_s16(S16Args a) {
+__device__ __forceinline__ void s16_conv_body(const S16Args& a, const int bid_, const int nblocks_, const int b) {
     static_assert(!TP || (EPI == TCS_EPI_LINEAR && KS == 3 && STRIDE == 1), "tap partials: 3x3 stride-1 LINEAR launches");
     static_assert(!RS || (KS == 3 && STRIDE == 1), "row split is for 3x3 stride-1 convolutions");
     static_assert(ROWS % RPW == 0 && (RPW == 1 || (!RS && EPI != TCS_EPI_DECONV2X && EPI != TCS_EPI_BLEND9)), "rows per wave");
@@ -479,8 +481,7 @@ __global__ __launch_bounds__(64 * ROWS / RPW, s16_min_waves(MT, EPI, RPW, TP)) v
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int ct, patch;
-    s16_block_tile(a, blockIdx.x, gridDim.x, patch, ct);
-    const int b = blockIdx.y;
+    s16_block_tile(a, bid_, nblocks_, patch, ct);
     const int y0 = (patch / a.npx) * ROWS, x0 = (patch % a.npx) * 32;
     const int Hp = a.Hin + 2, Wp = a.Win + 2;
     const unsigned plane = (unsigned)(Hp * Wp);                     // units per {hi|lo} plane
@@ -644,6 +645,38 @@ __global__ __launch_bounds__(64 * ROWS / RPW, s16_min_waves(MT, EPI, RPW, TP)) v
 #endif
 }
 
+template <int KS, int MT, int ROWS, int KSTEPS, int NSTAGE, int STRIDE, int EPI, int RS = 0, int RPW = 1, bool TP = false>
+__global__ __launch_bounds__(64 * ROWS / RPW, s16_min_waves(MT, EPI, RPW, TP)) void k_conv_s16(S16Args a) {
+    s16_conv_body<KS, MT, ROWS, KSTEPS, NSTAGE, STRIDE, EPI, RS, RPW, TP>(a, blockIdx.x, gridDim.x, blockIdx.y);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Two independent convolutions as ONE launch ("grouped launch").  Inside a refinement iteration pairs of layers that do not
+// depend on each other (the two 3x3 layers of the motion encoder's halves, the second layers of the gradient predictor's
+// stems, DispRefine's context branch beside its candidate stem) used to run as parallel branches of the captured graph — and
+// a dependency between two branches costs ~6 us on the branch that stays in its queue and ~11 us on the other one, against
+// ~1.5 us between two launches of one queue (profiles/r04_iteration_timeline.txt).  Here both problems share a grid: blocks
+// [0, n0) run problem 0's tile code, blocks [n0pad, gridDim.x) problem 1's (n0pad = n0 rounded up to a multiple of 8, so that
+// problem 1's XCD-contiguous block renumbering still sees block % 8 = its XCD; the <= 7 blocks in between exit at once).  The
+// two problems may be different template instances: the kernel is launched with the larger block, LDS and register budget;
+// surplus waves of the smaller instance exit before its first barrier (a barrier counts the waves that are still alive).
+// Same arithmetic, same order per output as two launches: results are bit-equal (tests/test_gpu_s16.py).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KS0, int MT0, int ROWS0, int KST0, int NST0, int EPI0, int KS1, int MT1, int ROWS1, int KST1, int NST1, int EPI1>
+__global__ __launch_bounds__(64 * (ROWS0 > ROWS1 ? ROWS0 : ROWS1),
+                             (s16_min_waves(MT0, EPI0, 1, false) < s16_min_waves(MT1, EPI1, 1, false) ? s16_min_waves(MT0, EPI0, 1, false)
+                                                                                                      : s16_min_waves(MT1, EPI1, 1, false)))
+void k_conv_s16_pair(S16Args a0, S16Args a1, int n0, int n0pad) {
+    const int bid = blockIdx.x;
+    if (bid < n0pad) {
+        if (bid >= n0 || (int)threadIdx.x >= 64 * ROWS0) return;
+        s16_conv_body<KS0, MT0, ROWS0, KST0, NST0, 1, EPI0>(a0, bid, n0, blockIdx.y);
+    } else {
+        if ((int)threadIdx.x >= 64 * ROWS1) return;
+        s16_conv_body<KS1, MT1, ROWS1, KST1, NST1, 1, EPI1>(a1, bid - n0pad, (int)gridDim.x - n0pad, blockIdx.y);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // fp32 NCHW <-> S16
 // ---------------------------------------------------------------------------------------------------------------------
@@ -696,6 +729,22 @@ __global__ __launch_bounds__(256) void k_s16_to_f32(const _Float16* __restrict__
 // ---------------------------------------------------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------------------------------------------------
+// A launch that tcs_conv2d_s16_group has asked to be PLANNED instead of issued: the chosen tile instance, its finished arguments and
+// launch geometry, and a way to issue it alone after all (when no pair kernel exists for the two instances).
+struct S16Plan {
+    bool filled;
+    long long key;                 // s16_key() of the instance
+    S16Args args;
+    int nblocks, threads, B;
+    size_t lds;
+    int (*launch_alone)(S16Args&, hipStream_t);
+};
+static thread_local S16Plan* g_s16_plan = nullptr;
+
+constexpr long long s16_key(int KS, int MT, int ROWS, int KSTEPS, int NSTAGE, int STRIDE, int EPI, int RS, int RPW, bool TP) {
+    return ((((((((((long long)KS * 10 + MT) * 10 + ROWS) * 10 + KSTEPS) * 10 + NSTAGE) * 10 + STRIDE) * 10 + EPI) * 10 + RS) * 10 + RPW) * 2 + (TP ? 1 : 0));
+}
+
 template <int KS, int MT, int ROWS, int KSTEPS, int NSTAGE, int STRIDE, int EPI, int RS = 0, int RPW = 1, bool TP = false>
 static int launch_s16(S16Args& a, hipStream_t s) {
     constexpr bool GATHER = KS == 1 && STRIDE == 2;                 // (as in the kernel)
@@ -704,16 +753,39 @@ static int launch_s16(S16Args& a, hipStream_t s) {
     constexpr size_t lds = (size_t)NSTAGE * NP * 1024;
     static_assert(lds <= 160 * 1024, "LDS budget");
     auto kern = k_conv_s16<KS, MT, ROWS, KSTEPS, NSTAGE, STRIDE, EPI, RS, RPW, TP>;
+    a.npx = tcs_cdiv(a.W, 32);
+    a.nct = a.nct32 / MT;
+    a.npatch = a.npx * tcs_cdiv(a.H, ROWS);
+    if (a.csplit > 0 && a.nct % a.csplit != 0) a.csplit = 1;
+    if (g_s16_plan && !g_s16_plan->filled) {                        // tcs_conv2d_s16_group: plan, do not launch
+        S16Plan& p = *g_s16_plan;
+        p.filled = true;
+        p.key = s16_key(KS, MT, ROWS, KSTEPS, NSTAGE, STRIDE, EPI, RS, RPW, TP);
+        p.args = a;
+        p.nblocks = a.npatch * a.nct; p.threads = 64 * ROWS / RPW; p.B = a.B; p.lds = lds;
+        p.launch_alone = &launch_s16<KS, MT, ROWS, KSTEPS, NSTAGE, STRIDE, EPI, RS, RPW, TP>;
+        return TCS_OK;
+    }
     (void)hipGetLastError();                                        // a stale error of an earlier runtime call is not ours
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return TCS_ELAUNCH;
     }
-    a.npx = tcs_cdiv(a.W, 32);
-    a.nct = a.nct32 / MT;
-    a.npatch = a.npx * tcs_cdiv(a.H, ROWS);
-    if (a.csplit > 0 && a.nct % a.csplit != 0) a.csplit = 1;
     hipLaunchKernelGGL(kern, dim3(a.npatch * a.nct, a.B), dim3(64 * ROWS / RPW), lds, s, a);
+    return tcs_launch_status();
+}
+
+template <int KS0, int MT0, int ROWS0, int KST0, int NST0, int EPI0, int KS1, int MT1, int ROWS1, int KST1, int NST1, int EPI1>
+static int launch_s16_pair(const S16Plan& p0, const S16Plan& p1, hipStream_t s) {
+    auto kern = k_conv_s16_pair<KS0, MT0, ROWS0, KST0, NST0, EPI0, KS1, MT1, ROWS1, KST1, NST1, EPI1>;
+    const size_t lds = p0.lds > p1.lds ? p0.lds : p1.lds;
+    (void)hipGetLastError();
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return TCS_ELAUNCH;
+    }
+    const int n0pad = (p0.nblocks + 7) & ~7;
+    hipLaunchKernelGGL(kern, dim3(n0pad + p1.nblocks, p0.B), dim3(64 * (ROWS0 > ROWS1 ? ROWS0 : ROWS1)), lds, s, p0.args, p1.args, p0.nblocks, n0pad);
     return tcs_launch_status();
 }
 
@@ -969,6 +1041,61 @@ int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
             return d->ksize == 3 ? launch_s16_cfg<3, 1, TCS_EPI_GRU_Q>(a, cfg, s) : launch_s16_cfg<1, 1, TCS_EPI_GRU_Q>(a, cfg, s);
         default: return TCS_EINVAL;
     }
+}
+
+// Pair kernels exist for the instance combinations the refinement loop groups (core/update.py); any other combination, and
+// anything the planner cannot take (ablation builds), runs as two ordinary launches: the results are the same either way.
+static int s16_launch_pair(const S16Plan& p0, const S16Plan& p1, hipStream_t s) {
+    constexpr int L = TCS_EPI_LINEAR;
+    constexpr long long k3412 = s16_key(3, 1, 4, 1, 2, 1, L, 0, 1, false), k3812 = s16_key(3, 1, 8, 1, 2, 1, L, 0, 1, false),
+                        k1422 = s16_key(1, 1, 4, 2, 2, 1, L, 0, 1, false);
+    if (p0.B == p1.B) {
+        if (p0.key == k3412 && p1.key == k3412) return launch_s16_pair<3, 1, 4, 1, 2, L, 3, 1, 4, 1, 2, L>(p0, p1, s);
+        if (p0.key == k3812 && p1.key == k1422) return launch_s16_pair<3, 1, 8, 1, 2, L, 1, 1, 4, 2, 2, L>(p0, p1, s);
+        if (p0.key == k1422 && p1.key == k3812) return launch_s16_pair<3, 1, 8, 1, 2, L, 1, 1, 4, 2, 2, L>(p1, p0, s);
+    }
+    return 1;           // no pair kernel
+}
+
+int tcs_conv2d_s16_group(const tcs_conv_s16_desc* const* descs, int n, tcs_stream_t stream) {
+    if (!descs || n < 1 || n > 2) return TCS_EINVAL;
+    if (n == 1) return tcs_conv2d_s16(descs[0], stream);
+    S16Plan plan[2];
+    for (int i = 0; i < 2; ++i) {
+        plan[i].filled = false;
+        g_s16_plan = &plan[i];
+        const int rc = tcs_conv2d_s16(descs[i], stream);
+        g_s16_plan = nullptr;
+        if (rc != TCS_OK) return rc;
+        if (!plan[i].filled) return TCS_EINVAL;
+    }
+    hipStream_t s = tcs_stream(stream);
+    const int rc = s16_launch_pair(plan[0], plan[1], s);
+    if (rc <= 0) return rc;
+    for (int i = 0; i < 2; ++i) {
+        const int r = plan[i].launch_alone(plan[i].args, s);
+        if (r != TCS_OK) return r;
+    }
+    return TCS_OK;
+}
+
+int tcs_conv2d_s16_group_fused(const tcs_conv_s16_desc* const* descs, int n) {
+    // diagnostic: 1 when tcs_conv2d_s16_group would issue these descriptors as ONE launch (tests assert the loop's pairs are)
+    if (!descs || n != 2) return 0;
+    S16Plan plan[2];
+    for (int i = 0; i < 2; ++i) {
+        plan[i].filled = false;
+        g_s16_plan = &plan[i];
+        const int rc = tcs_conv2d_s16(descs[i], nullptr);
+        g_s16_plan = nullptr;
+        if (rc != TCS_OK || !plan[i].filled) return 0;
+    }
+    constexpr int L = TCS_EPI_LINEAR;
+    const long long k3412 = s16_key(3, 1, 4, 1, 2, 1, L, 0, 1, false), k3812 = s16_key(3, 1, 8, 1, 2, 1, L, 0, 1, false),
+                    k1422 = s16_key(1, 1, 4, 2, 2, 1, L, 0, 1, false);
+    if (plan[0].B != plan[1].B) return 0;
+    return (plan[0].key == k3412 && plan[1].key == k3412) || (plan[0].key == k3812 && plan[1].key == k1422) ||
+           (plan[0].key == k1422 && plan[1].key == k3812);
 }
 
 }  // extern "C"

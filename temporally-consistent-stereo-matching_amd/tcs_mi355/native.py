@@ -99,12 +99,15 @@ SIGNATURES = {
     "tcs_instance_norm": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_f, c_int, c_fp, c_fp, c_fp]),
     "tcs_conv3x3_cout1": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp, c_fp]),
     "tcs_conv2d": (c_int, [C.POINTER(ConvDesc), c_fp]),
+    "tcs_conv2d_group": (c_int, [C.POINTER(C.POINTER(ConvDesc)), c_int, c_fp]),
     "tcs_s16_bytes": (c_sz, [c_int, c_int, c_int, c_int]),
     "tcs_s16_flags": (c_int, [C.POINTER(C.c_uint)]),
     "tcs_s16_flags_detail": (c_int, [C.POINTER(C.c_uint)]),
     "tcs_s16_from_f32": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_int, c_fp]),
     "tcs_s16_to_f32": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_fp]),
     "tcs_conv2d_s16": (c_int, [C.POINTER(ConvS16Desc), c_fp]),
+    "tcs_conv2d_s16_group": (c_int, [C.POINTER(C.POINTER(ConvS16Desc)), c_int, c_fp]),
+    "tcs_conv2d_s16_group_fused": (c_int, [C.POINTER(C.POINTER(ConvS16Desc)), c_int]),
     "tcs_avgpool3s2_s16": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_fp, c_int, c_fp]),
     "tcs_resize_bilinear_s16": (c_int, [c_fp, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_int, c_fp]),
     "tcs_instance_norm_s16_workspace_bytes": (c_sz, [c_int, c_int, c_int, c_int]),

@@ -415,6 +415,46 @@ def _desc(pc: PackedConv, srcs: Sequence[torch.Tensor]) -> nv.ConvDesc:
     return d
 
 
+_GROUP = None            # descriptors of the `with grouped():` block being recorded (LINEAR tcs_conv2d launches)
+
+
+class grouped:
+    """`with ops.grouped(): conv2d(...); conv2d(...)` — two INDEPENDENT tcs_conv2d layers issued as one launch at the end of the block
+    where the library has a grouped kernel for them (tcs_conv2d_group), otherwise one after the other; same results either way.
+    The fp32-tensor counterpart of tcs_mi355.s16.grouped."""
+
+    def __init__(self, enabled: bool = True):
+        self.enabled = enabled
+
+    def __enter__(self):
+        global _GROUP
+        if self.enabled:
+            if _GROUP is not None:
+                raise RuntimeError("ops.grouped() does not nest")
+            _GROUP = []
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _GROUP
+        if not self.enabled:
+            return False
+        descs, _GROUP = _GROUP, None
+        if et is not None or not descs:
+            return False
+        for i in range(0, len(descs), 2):
+            chunk = descs[i:i + 2]
+            arr = (C.POINTER(nv.ConvDesc) * len(chunk))(*[C.pointer(d) for d, _ in chunk])
+            nv.check(nv.lib().tcs_conv2d_group(arr, len(chunk), nv.stream()), "tcs_conv2d_group[" + " | ".join(n for _, n in chunk) + "]")
+        return False
+
+
+def _launch_conv(d, name: str):
+    if _GROUP is not None:
+        _GROUP.append((d, name))
+    else:
+        nv.check(nv.lib().tcs_conv2d(C.byref(d), nv.stream()), name)
+
+
 def conv2d(pc: PackedConv, srcs: Sequence[torch.Tensor], act: str = "none", addend=None, post_scale: float = 1.0,
            out: Optional[torch.Tensor] = None, out_coff: int = 0, stride: int = 1, out16=None, out16_group_offset: int = 0,
            image_pair: Optional[torch.Tensor] = None, in_transform: int = 0):
@@ -437,7 +477,7 @@ def conv2d(pc: PackedConv, srcs: Sequence[torch.Tensor], act: str = "none", adde
         d.epilogue, d.act, d.post_scale = EPI_LINEAR, ACT[act], float(post_scale)
         d.addend = nv.ptr(addend, "addend")
         d.out16, d.out16_groups, d.out16_group_offset = out16.ptr(), out16.G, int(out16_group_offset)
-        nv.check(nv.lib().tcs_conv2d(C.byref(d), nv.stream()), "tcs_conv2d[s16 out]")
+        _launch_conv(d, "tcs_conv2d[s16 out]")
         return out16
     if stride not in (1, 2):
         raise ValueError("stride 1 or 2")
@@ -454,7 +494,7 @@ def conv2d(pc: PackedConv, srcs: Sequence[torch.Tensor], act: str = "none", adde
     d.epilogue, d.act, d.post_scale = EPI_LINEAR, ACT[act], float(post_scale)
     d.addend = nv.ptr(addend, "addend")
     d.out, d.out_ctot, d.out_coff = nv.ptr(out, "out"), int(out.shape[1]), int(out_coff)
-    nv.check(nv.lib().tcs_conv2d(C.byref(d), nv.stream()), "tcs_conv2d")
+    _launch_conv(d, "tcs_conv2d")
     return out
 
 

@@ -27,6 +27,55 @@ def groups_for(C_: int) -> int:
     return (C_ + 15) // 16 * 2
 
 
+# ---- grouped launches (tcs_conv2d_s16_group) -------------------------------------------------------------------------
+_GROUP: Optional[list] = None        # descriptors of the `with grouped():` block being recorded
+
+
+class grouped:
+    """`with s16.grouped(): a = conv2d(...); b = conv2d(...)` — the (two) tcs_conv2d_s16 launches made inside the block are
+    INDEPENDENT layers (neither reads what the other writes) and go out as one launch at the end of the block where the library
+    has a pair kernel for their tile instances, otherwise one after the other; the tensors the calls return are valid after the
+    block.  What this replaces is a fork / join of two graph branches (tcs_mi355/streams.py): the pair keeps the concurrency
+    without the cross-queue dependencies.  `enabled=False` (A/B runs): launches happen at once, as without the block."""
+
+    def __init__(self, enabled: bool = True, report: bool = False):
+        self.enabled, self.report = enabled, report
+        self.fused: List[bool] = []          # with `report`: per pair, whether the library issued it as one launch
+
+    def __enter__(self):
+        global _GROUP
+        if self.enabled:
+            if _GROUP is not None:
+                raise RuntimeError("s16.grouped() does not nest")
+            _GROUP = []
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _GROUP
+        if not self.enabled:
+            return False
+        descs, _GROUP = _GROUP, None
+        if et is not None or not descs:
+            return False
+        for i in range(0, len(descs), 2):
+            chunk = descs[i:i + 2]
+            arr = (C.POINTER(nv.ConvS16Desc) * len(chunk))(*[C.pointer(d) for d, _ in chunk])
+            if self.report:
+                self.fused.append(len(chunk) == 2 and bool(nv.lib().tcs_conv2d_s16_group_fused(arr, 2)))
+            nv.check(nv.lib().tcs_conv2d_s16_group(arr, len(chunk), nv.stream()), "tcs_conv2d_s16_group[" + " | ".join(n for _, n in chunk) + "]")
+        return False
+
+
+def _launch(d, name: str):
+    """tcs_conv2d_s16 now, or at the end of the enclosing `grouped()` block."""
+    if _GROUP is not None:
+        _GROUP.append((d, name))
+    else:
+        nv.check(nv.lib().tcs_conv2d_s16(C.byref(d), nv.stream()), name)
+
+
+
+
 @dataclass
 class S16:
     data: torch.Tensor          # float16 [B, G, 2, H+2, W+2, 8]
@@ -210,7 +259,7 @@ def conv2d(pc: PackedConv, srcs: Sequence[S16], act: str = "none", addend: Optio
     if out32 is not None:
         d.out32, d.out_ctot, d.out_coff = nv.ptr(out32, "out32"), int(out32.shape[1]), int(out_coff)
     d.tile_cfg = int(tile_cfg)
-    nv.check(nv.lib().tcs_conv2d_s16(C.byref(d), nv.stream()), "tcs_conv2d_s16")
+    _launch(d, "tcs_conv2d_s16")
     return out16, out32
 
 
@@ -248,7 +297,7 @@ def deconv4x4s2(pc: PackedConv, srcs: Sequence[S16], out16: Optional[S16] = None
             raise ValueError("deconv4x4s2: `in_stats` must be an int64 tensor of [B, Cout, 2] (deconv_in_stats_workspace)")
         d.in_stats, d.in_eps = nv.ptr(in_stats, "in_stats", torch.int64), float(eps)
     d.tile_cfg = int(tile_cfg)
-    nv.check(nv.lib().tcs_conv2d_s16(C.byref(d), nv.stream()), "tcs_conv2d_s16[deconv2x]")
+    _launch(d, "tcs_conv2d_s16[deconv2x]")
     return out16
 
 
@@ -285,7 +334,7 @@ def gru_gates(pc_zr: PackedConv, srcs: Sequence[S16], h: S16, cz=None, cr=None, 
     d.out32, d.out_ctot, d.out_coff = nv.ptr(z_out, "z"), hid, 0
     d.out16, d.out16_groups, d.out16_group_offset = rh_out.ptr(), rh_out.G, 0
     d.tile_cfg = int(tile_cfg)
-    nv.check(nv.lib().tcs_conv2d_s16(C.byref(d), nv.stream()), "tcs_conv2d_s16[gru_zr]")
+    _launch(d, "tcs_conv2d_s16[gru_zr]")
     return z_out, rh_out
 
 
@@ -305,7 +354,7 @@ def gru_update(pc_q: PackedConv, srcs: Sequence[S16], h: S16, z: torch.Tensor, c
     if out32 is not None:
         d.out32, d.out_ctot, d.out_coff = nv.ptr(out32, "out32"), pc_q.cout, 0
     d.tile_cfg = int(tile_cfg)
-    nv.check(nv.lib().tcs_conv2d_s16(C.byref(d), nv.stream()), "tcs_conv2d_s16[gru_q]")
+    _launch(d, "tcs_conv2d_s16[gru_q]")
     return out
 
 
@@ -467,7 +516,7 @@ def conv1x1_blend(pc: PackedConv, srcs: Sequence[S16], cand9, disp_q, coords1, f
     if flow_x_s16 is not None:
         d.blend_flow16, d.blend_flow16_groups, d.blend_flow16_channel = flow_x_s16.ptr(), flow_x_s16.G, int(flow_x_channel)
     d.tile_cfg = int(tile_cfg)
-    nv.check(nv.lib().tcs_conv2d_s16(C.byref(d), nv.stream()), "tcs_conv2d_s16[blend9]")
+    _launch(d, "tcs_conv2d_s16[blend9]")
     return refined, delta
 
 

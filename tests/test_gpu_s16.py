@@ -401,6 +401,52 @@ def test_conv2d_s16_two_outputs_equal_separate_launches(dev):
         s16.conv2d(pc, [x16], out16=oa, out16b=ob, out16_split=16)
 
 
+def test_grouped_launch_equals_separate_launches(dev):
+    """tcs_conv2d_s16_group: two independent layers as ONE launch (block-index ranges, possibly two tile instances) — the pairs the
+    refinement loop groups instead of forking graph branches: two 3x3 64 -> 64 layers (BasicMotionEncoder.convc2 | convf2, the stems'
+    second layers; update.py:105-108,200-205) and a 3x3 next to a 1x1 (DispRefine.context_compress | disp_f_stem, update.py:293-297).
+    Bit-equal to the separate launches; a combination without a pair kernel falls back to two launches with the same result."""
+    from tcs_mi355 import ops, s16
+    gen = torch.Generator().manual_seed(11)
+
+    def layer(cin, cout, k, H, W, B=1):
+        x = torch.randn(B, cin, H, W, generator=gen)
+        w = torch.randn(cout, cin, k, k, generator=gen) * (2.0 / (k * k * cin)) ** 0.5
+        b = torch.randn(cout, generator=gen) * 0.1
+        return x, w, b, s16.to_s16(D(x, dev)), ops.pack_conv(D(w, dev), D(b, dev), "f16x3")
+
+    # (layer A, tile A, layer B, tile B, expect one launch); tiles: CSPLIT*100000 + MT*1000 + ROWS*100 + KSTEPS*10 + NSTAGE, 0 = heuristic
+    cases = [
+        ((64, 64, 3, 13, 37), 101412, (64, 64, 3, 13, 37), 101412, True),          # same instance, ragged small grid
+        ((32, 32, 3, 120, 160), 0, (64, 64, 3, 120, 160), 0, True),                # the stems' second layers at C2 size, heuristic tiles
+        ((192, 96, 3, 11, 40), 101812, (27, 96, 1, 11, 40), 101422, True),         # 3x3 8-row tile | 1x1 two-k-step tile
+        ((27, 96, 1, 120, 160), 0, (64, 96, 3, 120, 160), 0, True),                # ... at C2 size, 1x1 first, heuristic tiles
+        ((96, 96, 3, 120, 160), 0, (96, 96, 1, 120, 160), 0, True),                # context_compress[2] | disp_f_stem[2]
+        ((64, 64, 3, 9, 33), 101411, (64, 64, 3, 9, 33), 101412, False),           # no pair kernel for this combination: two launches
+    ]
+    for la, ta, lb, tb, fused in cases:
+        xa, wa, ba, xa16, pca = layer(*la)
+        xb, wb, bb, xb16, pcb = layer(*lb)
+        sep_a, _ = s16.conv2d(pca, [xa16], act="relu", tile_cfg=ta)
+        sep_b, _ = s16.conv2d(pcb, [xb16], act="relu", tile_cfg=tb)
+        with s16.grouped(report=True) as g:
+            grp_a, _ = s16.conv2d(pca, [xa16], act="relu", tile_cfg=ta)
+            grp_b, _ = s16.conv2d(pcb, [xb16], act="relu", tile_cfg=tb)
+        assert g.fused == [fused], (la, lb, g.fused)
+        assert torch.equal(grp_a.data, sep_a.data) and torch.equal(grp_b.data, sep_b.data), (la, lb)
+        assert maxdiff(grp_a.float(), torch.relu(F.conv2d(xa.double(), wa.double(), ba.double(), padding=la[2] // 2))) <= 2e-5
+        assert maxdiff(grp_b.float(), torch.relu(F.conv2d(xb.double(), wb.double(), bb.double(), padding=lb[2] // 2))) <= 2e-5
+    # batch sizes must match for one launch; otherwise two launches, same results
+    xa, wa, ba, xa16, pca = layer(64, 64, 3, 9, 33, B=2)
+    xb, wb, bb, xb16, pcb = layer(64, 64, 3, 9, 33, B=1)
+    with s16.grouped(report=True) as g:
+        oa, _ = s16.conv2d(pca, [xa16], tile_cfg=101412)
+        ob, _ = s16.conv2d(pcb, [xb16], tile_cfg=101412)
+    assert g.fused == [False]
+    assert maxdiff(oa.float(), F.conv2d(xa.double(), wa.double(), ba.double(), padding=1)) <= 2e-5
+    assert maxdiff(ob.float(), F.conv2d(xb.double(), wb.double(), bb.double(), padding=1)) <= 2e-5
+
+
 def test_deconv_fused_instance_norm_statistics(dev):
     """tcs_conv_s16_desc.in_stats: the transposed convolution adds fixed-point (sum x, sum x^2) of its own output to 64-bit accumulators
     (integer atomics), tcs_instance_norm_apply_s16 normalises with them (basic_layers.py:28-35,57).  The sums against fp64 on the CPU; the
