@@ -35,7 +35,7 @@ extern "C" {
 
 typedef void* tcs_stream_t;
 
-int tcs_abi_version(void);                 /* bumped when a signature changes */
+int tcs_abi_version(void);                 /* bumped when a signature changes (7: grouped launches, blend_warm_*) */
 const char* tcs_error_string(int code);
 
 /* ------------------------------------------------------------------------------------------------
@@ -389,6 +389,13 @@ typedef struct tcs_conv_s16_desc {
     float* tap_out;
     int tap_nout, tap_tiles;
     float tap_unscale;              /* 2^-scale_log2 given to tcs_pack_tap_weights */
+    /* TCS_EPI_BLEND9, optional: the skewed correlation pyramid of the frame (tcs_corr_build's pyr0..3; [B,H,W>>i,W] each, this launch's
+     * grid).  The lane that has just computed a pixel's new coords1 also issues the 4 x (2r+2) tap loads the NEXT tcs_corr_lookup will
+     * make for that pixel and discards the values: between two lookups ~300 MB of convolution traffic push the pyramid rows out of
+     * L2 and the Infinity Cache, and the lookup is three dependent memory round trips long, so where its taps come from decides
+     * its duration.  No effect on any result.  NULL = off. */
+    const float* blend_warm_pyr[4];
+    int blend_warm_radius;
 } tcs_conv_s16_desc;
 
 /* S16 glue of the loop: pool2x / interp (core/update.py:114-124), the up-blocks' InstanceNorm + LeakyReLU + skip

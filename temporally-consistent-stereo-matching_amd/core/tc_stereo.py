@@ -351,7 +351,10 @@ class TCStereo(nn.Module):
             at_flow = mark() if (run_ahead and not sp_join) else None
             disp_grad, context = self.disp_grad_refine.run(pool, g5, cands, dg_pre, lazy=lazy, slot=itr if itr < IN_SUM_SLOTS else None)
             last = itr == iters - 1
-            refined, up_mask, fused = self.disp_refine.run(pool, disp_grad, disp_q, nets[0], context, want_mask=last, motion=motion)
+            # (not on the last iteration: no lookup follows; "nowarm": A/B)
+            warm = corr_fn._pyr if (not last and "nowarm" not in _X and a.corr_levels == 4) else None
+            refined, up_mask, fused = self.disp_refine.run(pool, disp_grad, disp_q, nets[0], context, want_mask=last, motion=motion,
+                                                           warm_pyramid=warm, warm_radius=a.corr_radius)
             if run_ahead and not sp_join:
                 early32 = spawn(ahead, site="gru32", after=at_flow)     # enqueued last: never the first child of its fork point
             hu_delta = fused["delta_disp"]

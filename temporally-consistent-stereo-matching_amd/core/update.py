@@ -134,7 +134,7 @@ _X = set(t for t in os.environ.get("TCS_MI355_X", "").split(",") if t)
 GROUP = "nogroup" not in _X
 
 
-def conv16(pool, conv, srcs, act="none", addend=None, post_scale=1.0, out=None, want32=False, tag="o", addend16=None, pc=None):
+def conv16(pool, conv, srcs, act="none", addend=None, post_scale=1.0, out=None, want32=False, tag="o", addend16=None, pc=None, tile_cfg=0):
     """A Conv2d on S16 sources -> S16 (a pool buffer owned by this conv, or `out`), or fp32 NCHW when want32.
     `pc`: a K-slice of the layer's weights (packed16_part) when part of its input was already accumulated into `addend`."""
     a = srcs[0]
@@ -145,7 +145,7 @@ def conv16(pool, conv, srcs, act="none", addend=None, post_scale=1.0, out=None, 
         return s16.conv2d(pc, srcs, act=act, addend=addend, post_scale=post_scale, want32=True, stride=stride, addend16=addend16)[1]
     if out is None:
         out = pool.get((id(conv), tag), a.B, conv.out_channels, Ho, Wo, a.device)
-    return s16.conv2d(pc, srcs, act=act, addend=addend, post_scale=post_scale, out16=out, stride=stride, addend16=addend16)[0]
+    return s16.conv2d(pc, srcs, act=act, addend=addend, post_scale=post_scale, out16=out, stride=stride, addend16=addend16, tile_cfg=tile_cfg)[0]
 
 
 def conv32to16(pool, conv, x, act="none", tag="o", image_pair=None, in_transform=0):
@@ -673,7 +673,7 @@ class DispRefine(nn.Module):
         return refined, mask
 
     def run(self, pool, disp_grads: torch.Tensor, disp: torch.Tensor, context_disp: s16.S16, context_grad: s16.S16, want_mask=False,
-            motion: s16.S16 = None):
+            motion: s16.S16 = None, warm_pyramid=None, warm_radius: int = 4):
         """-> (refined fp32, mask fp32 or None, dict(delta_disp, coords1, flow_x)).  With `motion`, the next iteration's flow input
         (coords1 - x) also lands in channel 127 of that S16 buffer (tc_stereo.py:180, update.py:126)."""
         # the candidate stencil (with the residual head's last convolution finished from its tap partials) stays on the chain; behind it
@@ -687,11 +687,13 @@ class DispRefine(nn.Module):
         cc, ds = self.context_compress, self.disp_f_stem
         if GROUP:
             # context_compress (3x3, 192 -> 96 -> 96) beside disp_f_stem (1x1, 27 -> 96 -> 96), layer by layer as grouped launches
+            # (the 3x3 halves on the 4-row single-stage tile: a grouped launch allocates the larger LDS size of its two instances)
+            t3 = 101411 if (context_disp.H * context_disp.W >= 10000 and "ctx8" not in _X) else 0
             with s16.grouped():
-                c = conv16(pool, cc[0], [context_disp, context_grad], act="relu")
+                c = conv16(pool, cc[0], [context_disp, context_grad], act="relu", tile_cfg=t3)
                 d = conv16(pool, ds[0], [f27], act="relu")
             with s16.grouped():
-                context = conv16(pool, cc[2], [c])
+                context = conv16(pool, cc[2], [c], tile_cfg=t3)
                 disp_f = conv16(pool, ds[2], [d])
         else:
             context, disp_f = fork_join([lambda: conv16(pool, cc[2], [conv16(pool, cc[0], [context_disp, context_grad], act="relu")]),
@@ -702,8 +704,9 @@ class DispRefine(nn.Module):
         coords1, flow_x = torch.empty_like(disp), torch.empty_like(disp)
         if "noblendfuse" not in _X:
             # the blend runs as the epilogue of w_head's 1x1 convolution: one launch less on the iteration's critical chain
+            # `warm_pyramid` (the frame's correlation pyramid): the blend also touches the rows the next iteration's lookup reads
             refined, delta = s16.conv1x1_blend(packed16(self.w_head[2]), [w], cand9, disp, coords1, flow_x, flow_x_s16=motion,
-                                               flow_x_channel=127)
+                                               flow_x_channel=127, warm_pyramid=warm_pyramid, warm_radius=warm_radius)
         else:
             logits = conv16(pool, self.w_head[2], [w], want32=True)
             refined, delta = s16.softmax_blend(logits, cand9, disp, coords1, flow_x, flow_x_s16=motion, flow_x_channel=127)

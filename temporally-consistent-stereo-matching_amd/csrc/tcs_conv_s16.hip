@@ -66,6 +66,7 @@ struct S16Args {
     void* in_ws;                        // DECONV2X: fixed-point (sum, sum of squares) accumulators of the output, see s16_deconv_sums() (nullable)
     const float* tap_w; float* tap_out; int tap_nout, tap_ntile;   // LINEAR: tap partials of a following 3x3 conv to 1-2 channels (tcs_stencil.hip)
     float tap_unscale;
+    const float* warm_pyr0; const float* warm_pyr1; const float* warm_pyr2; const float* warm_pyr3; int warm_radius;   // BLEND9: see tcs_mi355.h
     int ablate;                         // diagnostic builds only (-DTCS_S16_ABLATE, tools/conv_s16_ablate.py): bit 0 skip the
                                         // input DMA, bit 1 skip the weight DMA, bit 2 skip operand reads + MFMAs (timing only)
 };
@@ -215,6 +216,28 @@ __device__ __forceinline__ void s16_epilogue_tile(const S16Args& a, int b, int c
                 _Float16* o16 = a.bl_f16 + s16_unit(b, a.bl_f16_groups, a.bl_f16_ch >> 3, 0, Hp, Wp, py, px) + (a.bl_f16_ch & 7);
                 o16[0] = hi[0];
                 o16[(size_t)Hp * Wp * 8] = lo[0];
+            }
+            if (a.warm_pyr0) {
+                // touch the rows of the skewed pyramid the next corr lookup reads for this pixel (k_corr_lookup's addressing, tcs_corr.hip):
+                // fire-and-forget loads into a register nobody reads — the lines travel towards L2 while this kernel drains
+#pragma unroll
+                for (int level = 0; level < 4; ++level) {
+                    const float* pl = level == 0 ? a.warm_pyr0 : (level == 1 ? a.warm_pyr1 : (level == 2 ? a.warm_pyr2 : a.warm_pyr3));
+                    const int Wl = W >> level;
+                    float x = c1 * (1.0f / (float)(1 << level));
+                    x = fminf(fmaxf(x, -1048576.f), 1048576.f);
+                    if (!(x == x)) x = -1048576.f;
+                    const int j0 = (int)floorf(x) - a.warm_radius, q = px >> level;
+                    const float* base = pl + ((size_t)(b * H + py) * Wl) * W + px;
+                    for (int t = 0; t <= 2 * a.warm_radius + 1; ++t) {
+                        const int j = j0 + t;
+                        int d = q - j;
+                        d = d < 0 ? d + Wl : (d >= Wl ? d - Wl : d);
+                        d = (j >= 0 && j < Wl && d >= 0 && d < Wl) ? d : 0;
+                        float sink;
+                        asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(base + (size_t)d * W) : "memory");
+                    }
+                }
             }
         }
     } else if (EPI == TCS_EPI_DECONV2X) {
@@ -972,6 +995,7 @@ int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
     a.ablate = d->tile_cfg / 1000000;                  // honoured by -DTCS_S16_ABLATE builds only
     a.bl_cand = nullptr; a.bl_cand_ctot = 0; a.bl_disp = nullptr; a.bl_refined = nullptr; a.bl_delta = nullptr; a.bl_coords1 = nullptr;
     a.bl_flow = nullptr; a.bl_f16 = nullptr; a.bl_f16_groups = 0; a.bl_f16_ch = 0;
+    a.warm_pyr0 = a.warm_pyr1 = a.warm_pyr2 = a.warm_pyr3 = nullptr; a.warm_radius = 0;
     if (!a.out16 && !a.out32 && !a.tap_out && d->epilogue != TCS_EPI_BLEND9) return TCS_EINVAL;
     // the packed weight image pads K to a multiple of 64 channels (tcs_conv_packed_floats_f16x3): nk may not exceed it
     const int kpack = ((d->Cin + 63) / 64) * 4;
@@ -1024,6 +1048,12 @@ int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
             a.bl_cand = d->blend_cand; a.bl_cand_ctot = d->blend_cand_ctot; a.bl_disp = d->blend_disp;
             a.bl_refined = d->blend_refined; a.bl_delta = d->blend_delta; a.bl_coords1 = d->blend_coords1; a.bl_flow = d->blend_flow_x;
             a.bl_f16 = reinterpret_cast<_Float16*>(d->blend_flow16); a.bl_f16_groups = d->blend_flow16_groups; a.bl_f16_ch = d->blend_flow16_channel;
+            if (d->blend_warm_pyr[0]) {
+                if (!d->blend_warm_pyr[1] || !d->blend_warm_pyr[2] || !d->blend_warm_pyr[3] || d->blend_warm_radius < 0 || d->blend_warm_radius > 16 ||
+                    d->W < 8) return TCS_EINVAL;
+                a.warm_pyr0 = d->blend_warm_pyr[0]; a.warm_pyr1 = d->blend_warm_pyr[1]; a.warm_pyr2 = d->blend_warm_pyr[2];
+                a.warm_pyr3 = d->blend_warm_pyr[3]; a.warm_radius = d->blend_warm_radius;
+            }
             return launch_s16_cfg<1, 1, TCS_EPI_BLEND9>(a, cfg, s);
         case TCS_EPI_DECONV2X:
             if (d->ksize != 3 || !a.out16 || d->Cout % 32 != 0) return TCS_EINVAL;
@@ -1048,9 +1078,13 @@ int tcs_conv2d_s16(const tcs_conv_s16_desc* d, tcs_stream_t stream) {
 static int s16_launch_pair(const S16Plan& p0, const S16Plan& p1, hipStream_t s) {
     constexpr int L = TCS_EPI_LINEAR;
     constexpr long long k3412 = s16_key(3, 1, 4, 1, 2, 1, L, 0, 1, false), k3812 = s16_key(3, 1, 8, 1, 2, 1, L, 0, 1, false),
-                        k1422 = s16_key(1, 1, 4, 2, 2, 1, L, 0, 1, false);
+                        k1422 = s16_key(1, 1, 4, 2, 2, 1, L, 0, 1, false), k3411 = s16_key(3, 1, 4, 1, 1, 1, L, 0, 1, false);
     if (p0.B == p1.B) {
         if (p0.key == k3412 && p1.key == k3412) return launch_s16_pair<3, 1, 4, 1, 2, L, 3, 1, 4, 1, 2, L>(p0, p1, s);
+        // 4-row single-stage 3x3 tile (31 KiB) beside the 1x1 tile (40 KiB): every workgroup of the launch is allocated the LARGER of
+        // the two LDS sizes, and with the 8-row two-stage 3x3 tile (80 KiB) the 1x1 half ran two workgroups per CU instead of four
+        if (p0.key == k3411 && p1.key == k1422) return launch_s16_pair<3, 1, 4, 1, 1, L, 1, 1, 4, 2, 2, L>(p0, p1, s);
+        if (p0.key == k1422 && p1.key == k3411) return launch_s16_pair<3, 1, 4, 1, 1, L, 1, 1, 4, 2, 2, L>(p1, p0, s);
         if (p0.key == k3812 && p1.key == k1422) return launch_s16_pair<3, 1, 8, 1, 2, L, 1, 1, 4, 2, 2, L>(p0, p1, s);
         if (p0.key == k1422 && p1.key == k3812) return launch_s16_pair<3, 1, 8, 1, 2, L, 1, 1, 4, 2, 2, L>(p1, p0, s);
     }
@@ -1092,10 +1126,11 @@ int tcs_conv2d_s16_group_fused(const tcs_conv_s16_desc* const* descs, int n) {
     }
     constexpr int L = TCS_EPI_LINEAR;
     const long long k3412 = s16_key(3, 1, 4, 1, 2, 1, L, 0, 1, false), k3812 = s16_key(3, 1, 8, 1, 2, 1, L, 0, 1, false),
-                    k1422 = s16_key(1, 1, 4, 2, 2, 1, L, 0, 1, false);
+                    k1422 = s16_key(1, 1, 4, 2, 2, 1, L, 0, 1, false), k3411 = s16_key(3, 1, 4, 1, 1, 1, L, 0, 1, false);
     if (plan[0].B != plan[1].B) return 0;
-    return (plan[0].key == k3412 && plan[1].key == k3412) || (plan[0].key == k3812 && plan[1].key == k1422) ||
-           (plan[0].key == k1422 && plan[1].key == k3812);
+    const long long a = plan[0].key, b = plan[1].key;
+    return (a == k3412 && b == k3412) || (a == k3812 && b == k1422) || (a == k1422 && b == k3812) || (a == k3411 && b == k1422) ||
+           (a == k1422 && b == k3411);
 }
 
 }  // extern "C"

@@ -486,7 +486,7 @@ int tcs_avgpool3s2(const float* x, int B, int C, int H, int W, float* out, tcs_s
     return tcs_launch_status();
 }
 
-int tcs_abi_version(void) { return 6; }
+int tcs_abi_version(void) { return 7; }
 
 const char* tcs_error_string(int code) {
     switch (code) {

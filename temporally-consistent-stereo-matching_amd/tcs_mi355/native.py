@@ -58,6 +58,7 @@ class ConvS16Desc(C.Structure):
         ("out16b", c_fp), ("out16b_groups", c_int), ("out16_split", c_int),
         ("in_stats", c_fp), ("in_eps", c_f),
         ("tap_weights", c_fp), ("tap_out", c_fp), ("tap_nout", c_int), ("tap_tiles", c_int), ("tap_unscale", c_f),
+        ("blend_warm_pyr", c_fp * 4), ("blend_warm_radius", c_int),
     ]
 
 

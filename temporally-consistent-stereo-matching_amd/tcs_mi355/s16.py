@@ -501,7 +501,7 @@ def softmax_blend(logits9, cand9, disp_q, coords1, flow_x, flow_x_s16: Optional[
 
 
 def conv1x1_blend(pc: PackedConv, srcs: Sequence[S16], cand9, disp_q, coords1, flow_x, flow_x_s16: Optional[S16] = None,
-                  flow_x_channel: int = 0, refined=None, delta=None, tile_cfg: int = 0):
+                  flow_x_channel: int = 0, refined=None, delta=None, tile_cfg: int = 0, warm_pyramid=None, warm_radius: int = 4):
     """w_head's last 1x1 convolution (-> 9 logits) with DispRefine's softmax blend as its epilogue (update.py:297-300 +
     tc_stereo.py:198-202): one launch instead of conv + `softmax_blend`, same arithmetic and outputs -> (refined, delta)."""
     if pc.cout != 9 or pc.ksize != 1:
@@ -515,6 +515,12 @@ def conv1x1_blend(pc: PackedConv, srcs: Sequence[S16], cand9, disp_q, coords1, f
     d.blend_coords1, d.blend_flow_x = nv.ptr(coords1, "coords1"), nv.ptr(flow_x, "flow_x")
     if flow_x_s16 is not None:
         d.blend_flow16, d.blend_flow16_groups, d.blend_flow16_channel = flow_x_s16.ptr(), flow_x_s16.G, int(flow_x_channel)
+    if warm_pyramid is not None:         # ops.CorrPyramid of this frame: the epilogue touches the rows the next lookup will read
+        if (warm_pyramid.B, warm_pyramid.H, warm_pyramid.W) != (d.B, d.H, d.W):
+            raise ValueError("conv1x1_blend: `warm_pyramid` has another grid")
+        for i in range(4):
+            d.blend_warm_pyr[i] = nv.ptr(warm_pyramid.levels[i], "pyr")
+        d.blend_warm_radius = int(warm_radius)
     d.tile_cfg = int(tile_cfg)
     _launch(d, "tcs_conv2d_s16[blend9]")
     return refined, delta

@@ -287,6 +287,23 @@ def test_conv1x1_blend_equals_conv_then_blend(dev):
             outs.append((r, dl, c1, fx, buf.data.clone()))
         for a_, b_ in zip(*outs):
             assert bool((a_ == b_).all())
+        # the optional pyramid warm-up (blend_warm_pyr: the lane also issues the next lookup's tap loads and discards them) changes
+        # no output — also with candidates that put the new coordinate far outside the row, NaN included (addresses are clamped)
+        if W % 8 == 0 or True:
+            pyr = ops.corr_build(D(torch.randn(B, 16, H, W, generator=gen), dev), D(torch.randn(B, 16, H, W, generator=gen), dev))
+            wild = cand.clone()
+            wild[:, :, 0, :4] = 1e9
+            wild[:, :, 1, :4] = -1e9
+            wild[:, :, 2, :2] = float("nan")
+            for cnd in (cand, wild):
+                res = []
+                for warm in (None, pyr):
+                    c1, fx = torch.empty(B, 1, H, W, device=dev), torch.empty(B, 1, H, W, device=dev)
+                    r, dl = s16.conv1x1_blend(pc, [x16], cnd, disp, c1, fx, warm_pyramid=warm)
+                    res.append((r, dl, c1, fx))
+                torch.cuda.synchronize()
+                for a_, b_ in zip(*res):
+                    assert bool(((a_ == b_) | (a_.isnan() & b_.isnan())).all())
         # and against fp64 arithmetic
         logits = F.conv2d(x16.float().double().cpu(), w.double(), b.double())
         ref = (torch.softmax(logits, 1) * cand.double().cpu()).sum(1, keepdim=True)
@@ -422,6 +439,7 @@ def test_grouped_launch_equals_separate_launches(dev):
         ((192, 96, 3, 11, 40), 101812, (27, 96, 1, 11, 40), 101422, True),         # 3x3 8-row tile | 1x1 two-k-step tile
         ((27, 96, 1, 120, 160), 0, (64, 96, 3, 120, 160), 0, True),                # ... at C2 size, 1x1 first, heuristic tiles
         ((96, 96, 3, 120, 160), 0, (96, 96, 1, 120, 160), 0, True),                # context_compress[2] | disp_f_stem[2]
+        ((192, 96, 3, 120, 160), 101411, (27, 96, 1, 120, 160), 0, True),          # ... with the 4-row single-stage 3x3 tile the loop uses
         ((64, 64, 3, 9, 33), 101411, (64, 64, 3, 9, 33), 101412, False),           # no pair kernel for this combination: two launches
     ]
     for la, ta, lb, tb, fused in cases:
