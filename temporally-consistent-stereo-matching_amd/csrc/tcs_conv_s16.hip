@@ -218,8 +218,10 @@ __device__ __forceinline__ void s16_epilogue_tile(const S16Args& a, int b, int c
                 o16[(size_t)Hp * Wp * 8] = lo[0];
             }
             if (a.warm_pyr0) {
-                // touch the rows of the skewed pyramid the next corr lookup reads for this pixel (k_corr_lookup's addressing, tcs_corr.hip):
-                // fire-and-forget loads into a register nobody reads — the lines travel towards L2 while this kernel drains
+                // touch the rows of the skewed pyramid the next corr lookup reads for this pixel (k_corr_lookup's addressing, tcs_corr.hip).
+                // The loads' destination is ONE register that stays allocated ("+v") until they have all come back: a load that returns
+                // into a register the compiler has meanwhile given to an address of a later load faults (it did, once).
+                float sink = 0.f;
 #pragma unroll
                 for (int level = 0; level < 4; ++level) {
                     const float* pl = level == 0 ? a.warm_pyr0 : (level == 1 ? a.warm_pyr1 : (level == 2 ? a.warm_pyr2 : a.warm_pyr3));
@@ -234,10 +236,10 @@ __device__ __forceinline__ void s16_epilogue_tile(const S16Args& a, int b, int c
                         int d = q - j;
                         d = d < 0 ? d + Wl : (d >= Wl ? d - Wl : d);
                         d = (j >= 0 && j < Wl && d >= 0 && d < Wl) ? d : 0;
-                        float sink;
-                        asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(base + (size_t)d * W) : "memory");
+                        asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(base + (size_t)d * W) : "memory");
                     }
                 }
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
             }
         }
     } else if (EPI == TCS_EPI_DECONV2X) {
