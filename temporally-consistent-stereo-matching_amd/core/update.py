@@ -591,12 +591,21 @@ class DispGradPredictor(nn.Module):
         per iteration; two memsets per frame instead of two statistics launches per iteration)."""
         for blk in (self.conv_16_8, self.conv_8_4):
             up_block_sums(pool, blk, B, device).zero_()
+        self._slots_used = set()
 
     def run(self, pool, g5: torch.Tensor, cands: torch.Tensor, pre, lazy: bool = False, slot=None):
         """g5 = 5 * gradient [N,2,H,W] fp32, cands [N,32,H,W] fp32, pre: `prepare(pool, clist)` of the 3 S16 context tensors
         (64 ch at 1/4, 1/8, 1/16) -> (gradient fp32 [N,2,H,W], context S16 [N,64,H,W]).  `lazy`: the gradient as
         (s16.Taps of residual_head[2], g5, 0.2) for DispRefine.run, which finishes (5*grad + residual) / 5 in its candidate stencil.
         `slot`: see up_block16 (the frame loop passes its iteration index after `begin_frame`)."""
+        # The accumulators only ADD: a set may be used once between two begin_frame() calls.  A slot that was already used (a second run
+        # with the same index, a caller that never called begin_frame) or lies beyond IN_SUM_SLOTS falls back to the statistics launch.
+        used = self.__dict__.setdefault("_slots_used", None)
+        if slot is not None and (used is None or slot in used or not 0 <= int(slot) < IN_SUM_SLOTS):
+            slot = None
+        if slot is not None:
+            used.add(slot)
+
         def feat(conv, srcs, share):
             n = sum(t.C for t in srcs)
             return conv16(pool, conv, srcs, act="relu", addend=share, pc=packed16_part(conv, ((0, n),), with_bias=False))

@@ -18,7 +18,27 @@ from typing import Callable, List, Sequence
 
 import torch
 
+def _hw_queues_allow_forks() -> bool:
+    """A captured frame with parallel branches needs >= 3 hardware queues.  ROCm's graph executor submits each launch list in batches
+    of consecutive nodes, and a batch of the main list can contain a wait for a side-list node that is submitted after it: on separate
+    hardware queues that is a pending barrier packet, on ONE in-order queue (or when two lists that wait for each other share one of two)
+    it is a deadlock — with GPU_MAX_HW_QUEUES=1 or 2 no frame ever completed (profiles/r03_ab_logs.txt).  ROCclr's default is 4; when
+    the environment asks for fewer, forking is switched off (one launch list: correct on any queue count, ~2 ms per frame slower)."""
+    v = os.environ.get("GPU_MAX_HW_QUEUES", "").strip()
+    if not v:
+        return True
+    try:
+        return int(v) >= 3
+    except ValueError:
+        return True
+
+
 ENABLED = os.environ.get("TCS_MI355_STREAMS", "1") == "1"
+if ENABLED and not _hw_queues_allow_forks():
+    import warnings
+    warnings.warn("tcs_mi355: GPU_MAX_HW_QUEUES < 3 — parallel graph branches would deadlock on this few hardware queues; running every frame as "
+                  "one launch list (TCS_MI355_STREAMS=0 behaviour)")
+    ENABLED = False
 SITES = os.environ.get("TCS_MI355_FORK_SITES", "all").split(",")       # diagnostic: restrict forking to named call sites
 OFF = set(t for t in os.environ.get("TCS_MI355_FORK_OFF", "").split(",") if t)      # diagnostic (A/B runs): call sites that run serially
 # Capture order at a fork.  ROCm's graph executor cuts a captured graph into launch lists by a depth-first walk that follows a node's

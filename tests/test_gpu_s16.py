@@ -502,6 +502,55 @@ def test_deconv_fused_instance_norm_statistics(dev):
                 assert maxdiff(y.float(), ref) <= max(3e-5, tol), (cout, tc)
     with pytest.raises(ValueError):                      # fp32 workspaces are round 3's first design
         s16.deconv4x4s2(pc, [x16], in_stats=torch.zeros(B * cout * 4, device=dev))
+    # small-magnitude channels (sigma ~ 1e-3 next to O(1) ones): the squares are accumulated in units of 2^-16 PER TILE SUM (not per element),
+    # so a channel whose tile sums of x^2 are ~1e-4 still keeps ~3 digits; the normalised output must match the two-launch path
+    cin, cout, H, W = 96, 64, 60, 80
+    wt = torch.randn(cin, cout, 4, 4, generator=gen) * (1.0 / (cin * 4)) ** 0.5
+    wt[:, ::4] *= 1e-3                                    # every fourth output channel three orders of magnitude smaller
+    x = torch.randn(1, cin, H, W, generator=gen)
+    pc = ops.pack_deconv4x4s2(D(wt, dev))
+    x16 = s16.to_s16(D(x, dev))
+    ws = s16.deconv_in_stats_workspace(1, cout, H, W, dev)
+    y = s16.deconv4x4s2(pc, [x16], in_stats=ws)
+    two = s16.instance_norm(y, act="leaky")
+    got = s16.instance_norm_apply(y, ws, act="leaky")
+    ref = F.leaky_relu(F.instance_norm(F.conv_transpose2d(x.double(), wt.double(), stride=2, padding=1), eps=1e-5), 0.01)
+    d_small = (got.float()[:, ::4].cpu().double() - ref[:, ::4]).abs().max()
+    d_big = (got.float()[:, 1::4].cpu().double() - ref[:, 1::4]).abs().max()
+    # the small channels: var ~ 1e-6 is of the order of eps = 1e-5, so the normalised values are O(0.3) and an error of the fixed-point
+    # sums shows up directly; 1e-3 absolute there, the usual 3e-5 on the ordinary channels
+    assert float(d_big) <= 3e-5 and float(d_small) <= 1e-3, (float(d_big), float(d_small))
+    assert maxdiff(got.float()[:, 1::4], two.float()[:, 1::4]) <= 2e-6
+
+
+def test_gradient_predictor_instance_norm_slots_are_single_use(dev):
+    """DispGradPredictor.run(slot=k) lets the transposed convolutions accumulate their InstanceNorm sums into set k of per-frame accumulators,
+    which only ADD: a slot index may be used once between two begin_frame() calls.  A repeated index, an index beyond IN_SUM_SLOTS
+    (iterations > 64) or a run without begin_frame() must fall back to the statistics launch and give the same result, never a silently
+    wrong mean / rstd."""
+    from argparse import Namespace
+    from core.update import IN_SUM_SLOTS, DispGradPredictor, pool_of
+    from tcs_mi355 import ops, s16
+    torch.manual_seed(3)
+    m = DispGradPredictor(Namespace()).to(dev).eval()
+    pool = pool_of(m)
+    gen = torch.Generator().manual_seed(4)
+    B, H, W = 1, 32, 48
+    g5 = D(torch.randn(B, 2, H, W, generator=gen), dev)
+    disp = D(torch.rand(B, 1, H, W, generator=gen) * 20, dev)
+    cands = ops.grad_candidates(disp)
+    clist = [s16.to_s16(D(torch.randn(B, 64, H >> i, W >> i, generator=gen), dev)) for i in range(3)]
+    with torch.no_grad():
+        pre = m.prepare(pool, clist)
+        ref_g, ref_c = m.run(pool, g5, cands, pre, slot=None)                 # statistics launches
+        ref_g, ref_c = ref_g.clone(), ref_c.float().clone()
+        m.begin_frame(pool, B, dev)                                            # (each call is compared right away: pool buffers are reused)
+        for k in (0, 0, 1, IN_SUM_SLOTS, IN_SUM_SLOTS + 1, 1):
+            g, c = m.run(pool, g5, cands, pre, slot=k)
+            assert maxdiff(g, ref_g) <= 2e-5 and maxdiff(c.float(), ref_c) <= 2e-5, k
+        m.__dict__.pop("_slots_used", None)                                    # a caller that never called begin_frame
+        g, c = m.run(pool, g5, cands, pre, slot=3)
+        assert maxdiff(g, ref_g) <= 2e-5 and maxdiff(c.float(), ref_c) <= 2e-5
 
 
 def test_tap_partials_fold_a_narrow_3x3_convolution_into_its_producer(dev):
