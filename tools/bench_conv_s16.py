@@ -45,6 +45,7 @@ SHAPES = [  # name, (cins...), cout, k, H, W, epilogue, stride
     ("half 96->96", (96,), 96, 3, 240, 320, "lin", 1),          # layer2
     ("quarter 128->128", (128,), 128, 3, 120, 160, "lin", 1),   # layer3 / heads
     ("deconv 128->96", (128,), 96, 3, 30, 40, "deconv", 1),
+    ("conv128->128/16", (128,), 128, 3, 30, 40, "lin", 1),       # gradient predictor conv_16_16 (context share precomputed)
 ]
 CFGS3 = [101412, 101812, 101411, 102411, 101811, 102812, 102512]
 CFGS1 = [1422, 101422, 2422, 102422, 202422, 1442, 2442, 102442]
