@@ -297,12 +297,13 @@ class TCStereo(nn.Module):
         # share -> interp -> gru08 -> flow head -> gradient predictor -> refinement -> blend(i) — is the FIRST branch of every fork, so
         # that it stays in one launch list of the captured graph (tcs_mi355/streams.py: MAIN_FIRST); what has slack hangs off it as side
         # branches: [corr lookup -> motion encoder] (needs only coords1 / the flow of the previous blend, due at gru08), and [gru32 of
-        # the NEXT iteration -> the share of gru16 that reads only net16 / interp(net32)] (needs net16, due ~400 us later), which starts
-        # behind the flow head's stencil, beside the gradient predictor's small launches, not beside gru08's 600-workgroup ones.
-        # A/B tokens: "encmain" = the encoder chain first and the coarse chain as the side branch (rounds 2-3), "sp_join" = the early
-        # gru32 branch starts at the iteration's join (beside gru08) as in rounds 2-3.
+        # the NEXT iteration -> the share of gru16 that reads only net16 / interp(net32)] (needs net16, due ~500 us later), forked at the
+        # iteration's join but enqueued after gru08 / the flow head, so that gru08 and not this branch continues the launch list.
+        # A/B tokens: "encmain" = the encoder chain first and the coarse chain as the side branch (rounds 2-3), "sp_flow" = the early
+        # gru32 branch forks behind the flow head's stencil instead (26.69 against 26.42 ms per frame, three rounds on one box: on this
+        # stack the branch starts ~430 us into the iteration whichever node it hangs off, and the fork at the join is the cheaper one).
         enc_main = "encmain" in _X
-        sp_join = "sp_join" in _X
+        sp_join = "sp_flow" not in _X
         for itr in range(iters):
             def enc_branch():
                 corr = corr_fn(coords1)
