@@ -4,7 +4,7 @@ Same constructor (an argparse-style Namespace), same sub-module names (reference
 with strict=True), same `forward(image1, image2, iters, params, test_mode, frame_id)` signature and
 the same test-mode output dict, so evaluate_stereo.py's loop (evaluate_stereo.py:170-197) runs
 unchanged.  One optional addition: `prefetch(next_image1, next_image2)` for video loops (the next frame's
-image-only stage overlaps the current frame's refinement loop).  What differs is underneath: correlation build/lookup, the temporal warp, the GRU update
+image-only stage is enqueued ahead of time).  What differs is underneath: correlation build/lookup, the temporal warp, the GRU update
 step, both U-Nets, every stencil and the feature extractor's convolutions are hand-written HIP kernels
 for gfx950 (libtcs_mi355.so); PyTorch-ROCm owns tensors, streams and graph capture.
 
@@ -122,15 +122,14 @@ class TCStereo(nn.Module):
 
     @torch.no_grad()
     def prefetch(self, image1, image2, first=False, inputs_ready=False):
-        """Optional, for callers that know the next frame (a video loop): start the part of a frame that depends on nothing but its
-        two images — feature / context networks, correlation pyramid, context convolutions (tc_stereo.py:101-116,147-149) — on a
-        second stream, beside the refinement loop of the frame in flight.  The next `forward` with the SAME image tensors (same
-        objects, unmodified) picks the result up; any other call simply extracts again.  `first`: that frame will be called with
-        params=None (start of a sequence: the arg-max prior is then built with the correlation volume).
-        Call it right AFTER the `forward` it is to overlap with and pass `inputs_ready=True` when the images were complete on the
-        device before that `forward` was called (frames resident in memory): the extraction then starts when that frame's
-        refinement loop starts (its short state-dependent head runs undisturbed).  With `inputs_ready=False` it is ordered behind
-        everything queued on the current stream so far.  Results are identical with and without it."""
+        """Optional, for callers that know the next frame (a video loop): enqueue the part of a frame that depends on nothing but its
+        two images — feature / context networks, correlation pyramid, context convolutions (tc_stereo.py:101-116,147-149) — right
+        behind the frame in flight, so that its host-side launch work is done while the GPU is still busy with that frame (on this
+        stack the stage cannot run BESIDE the loop on the GPU).  The next `forward` with the SAME image tensors
+        (same objects, unmodified) picks the result up; any other call simply extracts again.  `first`: that frame will be called with
+        params=None (start of a sequence: the arg-max prior is then built with the correlation volume).  Call it right AFTER the
+        `forward` it follows.  `inputs_ready` is kept for callers of round 3's two-stream version and no longer changes anything when
+        the stage runs on the caller's stream.  Results are identical with and without the call."""
         if not image1.is_cuda:
             raise RuntimeError("TCStereo.prefetch needs HIP device tensors; there is no CPU fallback")
         self._pipeline().prefetch(image1, image2, first=bool(first), use_graph=self._graph_mode(), inputs_ready=bool(inputs_ready))

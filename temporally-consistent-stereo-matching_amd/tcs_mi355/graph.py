@@ -4,7 +4,7 @@ A frame has two parts.  EXTRACT — image normalisation, feature / context netwo
 (core/tc_stereo.py:101-116,147-149 of the reference) — depends on nothing but the two images.  REFINE — the temporal warp or
 arg-max prior, disparity completion, hidden-state warp and the refinement loop (tc_stereo.py:119-229) — needs EXTRACT's
 features and the previous frame's outputs.  Frames of a sequence are serial through REFINE only, so the EXTRACT of frame t+1
-can run while the REFINE of frame t still does: `prefetch(image1, image2)` launches it on a second stream into the free one
+can be enqueued while the REFINE of frame t still runs: `prefetch(image1, image2)` launches it into the free one
 of two feature slots, and the following `__call__` with the same image tensors finds it there.  What that buys, as measured
 (profiles/r03_frame_phases.txt): the HOST-side launch work of the next EXTRACT (0.35-0.6 ms per frame) leaves
 the frame's serial path; on the GPU the extraction does NOT run beside the loop (its first kernel starts 0.4-1.3 ms after the
