@@ -185,7 +185,7 @@ def lookup_roofline(probe, snapshots, burst, pixels):
     # PMC traffic and rocprofv3's own durations come from the committed profile of this same command (profiles/README.md):
     # bench.py cannot run the profiler on itself.  rocprofv3's per-kernel interval includes ~2 us of dispatch / completion
     # (trivial kernels read 4.5-5 us in the same trace), so frac_rocprof is a lower bound of the kernel's own rate.
-    for name in ("r03_lookup_pmc.json", "r02_lookup_pmc.json"):
+    for name in ("r04_lookup_pmc.json", "r03_lookup_pmc.json", "r02_lookup_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 pmc = json.load(f)
