@@ -9,6 +9,9 @@
 //   mode G   L launches in a replayed HIP graph, one layer each (what the frame does today)
 //   mode R1  one launch; plain stores, release fence (buffer_wbl2 sc1), counter += 1; consumers poll the three counters, acquire fence (buffer_inv sc1)
 //   mode R2  one launch; write-through stores (agent-scope atomic stores: sc1), s_waitcnt, counter += 1; consumers poll, then read with sc1 loads
+//   mode R3  one launch, XCD-LOCAL handoff: tiles are dealt to the XCDs in contiguous strips (workgroup w runs on XCD w % 8 and owns tile (w % 8) * T/8 + w / 8), so
+//            the neighbours of an interior tile were produced on the same XCD: plain stores (the L1 writes through to the XCD's L2) + s_waitcnt, counters as L2
+//            atomics, consumers read with sc0 loads (L1 bypassed, L2 hit) — no trip to the memory side.  Only the two tiles at each strip border use the sc1 path.
 // Spins are BOUNDED (a timeout sets an error word and falls through): a protocol bug is a wrong checksum, never a hung GPU.  The three modes must
 // produce the same checksum — a stale read across XCDs shows up there.
 // Build: hipcc -O3 --offload-arch=gfx950 chain_flags.hip -o chain_flags ; run on the GPU box: chain_flags [tiles] [layers]
@@ -39,7 +42,18 @@ __device__ __forceinline__ unsigned long long mix(unsigned long long a, unsigned
     return v + (unsigned long long)((int)f & 1);
 }
 
-template <int MODE>   // 0: plain loads / stores (one layer per launch); 1: plain + fences; 2: sc1 stores and loads
+__device__ __forceinline__ unsigned long long ld_sc0(const unsigned long long* p) {        // group scope: misses the L1, served by this XCD's L2
+    unsigned long long v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc0" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ unsigned ld32_sc0(const unsigned* p) {
+    unsigned v;
+    asm volatile("global_load_dword %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+template <int MODE>   // 0: plain loads / stores (one layer per launch); 1: plain + fences; 2: sc1 stores and loads; 3: XCD-local (sc0 loads), sc1 at strip borders
 __device__ __forceinline__ void layer(const Args& a, int l, int t) {
     const int tid = threadIdx.x;
     const unsigned long long* in = a.buf + (size_t)(l - 1) * a.T * TILE_U64;
@@ -53,11 +67,19 @@ __device__ __forceinline__ void layer(const Args& a, int l, int t) {
             x = __hip_atomic_load(in + (size_t)tl * TILE_U64 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             y = __hip_atomic_load(in + (size_t)t * TILE_U64 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             z = __hip_atomic_load(in + (size_t)tr * TILE_U64 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (MODE == 3) {
+            const int S = a.T / 8, strip = t / S;
+            const bool lx = tl / S != strip, rx = tr / S != strip;                 // that neighbour belongs to another XCD's strip
+            x = lx ? __hip_atomic_load(in + (size_t)tl * TILE_U64 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ld_sc0(in + (size_t)tl * TILE_U64 + k);
+            y = ld_sc0(in + (size_t)t * TILE_U64 + k);
+            z = rx ? __hip_atomic_load(in + (size_t)tr * TILE_U64 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ld_sc0(in + (size_t)tr * TILE_U64 + k);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             x = in[(size_t)tl * TILE_U64 + k]; y = in[(size_t)t * TILE_U64 + k]; z = in[(size_t)tr * TILE_U64 + k];
         }
         const unsigned long long v = mix(x, y, z, a.work, a.salt);
-        if (MODE == 2) __hip_atomic_store(out + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool border = MODE == 3 && (t % (a.T / 8) == 0 || t % (a.T / 8) == a.T / 8 - 1);     // read by another XCD: write through
+        if (MODE == 2 || border) __hip_atomic_store(out + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else out[k] = v;
     }
 }
@@ -66,7 +88,7 @@ __global__ __launch_bounds__(256) void k_one_layer(Args a, int l) { a.salt = *a.
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k_resident(Args a) {
-    const int t = blockIdx.x;
+    const int t = MODE == 3 ? (int)(blockIdx.x & 7) * (a.T / 8) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     for (int l = 1; l <= a.L; ++l) {
         if (l > 1) {
             // wait for the three producer tiles of layer l-1 (threads 0..2 poll one counter each, bounded)
@@ -75,7 +97,10 @@ __global__ __launch_bounds__(256) void k_resident(Args a) {
                 if (q >= 0 && q < a.T) {
                     const unsigned* c = a.cnt + (size_t)(l - 1) * a.T + q;
                     int spins = 0;
-                    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.epoch) {
+                    const int S_ = a.T / 8;
+                    const bool q_border = q % S_ == 0 || q % S_ == S_ - 1;              // border tiles signal (and store) through the memory side
+                    const bool local = MODE == 3 && q / S_ == t / S_ && !q_border;
+                    while ((local ? ld32_sc0(c) : __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < a.epoch) {
                         __builtin_amdgcn_s_sleep(1);
                         if (++spins > (1 << 22)) { atomicOr(a.err, 1u); break; }
                     }
@@ -89,7 +114,11 @@ __global__ __launch_bounds__(256) void k_resident(Args a) {
             if (MODE == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // buffer_wbl2 sc1 + wait
             else __builtin_amdgcn_s_waitcnt(0);                                    // the write-through stores have been acknowledged
             __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_fetch_add(a.cnt + (size_t)l * a.T + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x == 0) {
+                const bool border = MODE == 3 && (t % (a.T / 8) == 0 || t % (a.T / 8) == a.T / 8 - 1);
+                if (MODE == 3 && !border) __hip_atomic_fetch_add(a.cnt + (size_t)l * a.T + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // L2 atomic
+                else __hip_atomic_fetch_add(a.cnt + (size_t)l * a.T + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
@@ -122,7 +151,8 @@ static int run(const char* name, int mode, Args a, hipStream_t s, unsigned long 
             a.salt = r;
             CHECK(hipEventRecord(e0, s));
             if (mode == 1) hipLaunchKernelGGL(k_resident<1>, dim3(a.T), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL(k_resident<2>, dim3(a.T), dim3(256), 0, s, a);
+            else if (mode == 2) hipLaunchKernelGGL(k_resident<2>, dim3(a.T), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL(k_resident<3>, dim3(a.T), dim3(256), 0, s, a);
             CHECK(hipEventRecord(e1, s));
             CHECK(hipStreamSynchronize(s));
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -153,17 +183,19 @@ int main(int argc, char** argv) {
     CHECK(hipMemset(a.err, 0, 4));
     std::vector<unsigned long long> h0((size_t)T * TILE_U64);
     for (size_t i = 0; i < h0.size(); ++i) h0[i] = i * 2654435761ull + 12345;
-    for (int work : {0, 600, 2400}) {                   // ~0 / ~1.5 / ~6 us of dependent FMAs per layer
+    for (int work : {0, 40, 160}) {                     // dependent FMAs per element (8 elements per thread): 0 / ~8 / ~25 us per layer
         a.work = work;
         printf("tiles %d (x 256 threads), layers %d, work %d FMAs per element chain:\n", T, L, work);
-        unsigned long long s0 = 0, s1 = 0, s2 = 0;
-        for (int mode = 0; mode < 3; ++mode) {
+        unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        for (int mode = 0; mode < 4; ++mode) {
+            if (mode == 1 && getenv("CHAIN_SKIP_R1")) { s1 = s0; continue; }
             CHECK(hipMemset(a.buf, 0, (size_t)(L + 1) * T * TILE_U64 * 8));
             CHECK(hipMemcpy(a.buf, h0.data(), h0.size() * 8, hipMemcpyHostToDevice));
-            const char* names[3] = {"G : one launch per layer (graph replay)", "R1: resident, plain stores + agent fences", "R2: resident, sc1 stores / loads"};
-            if (run(names[mode], mode, a, s, mode == 0 ? &s0 : (mode == 1 ? &s1 : &s2))) return 1;
+            const char* names[4] = {"G : one launch per layer (graph replay)", "R1: resident, plain stores + agent fences", "R2: resident, sc1 stores / loads",
+                                    "R3: resident, XCD-local strips (sc0 loads)"};
+            if (run(names[mode], mode, a, s, mode == 0 ? &s0 : (mode == 1 ? &s1 : (mode == 2 ? &s2 : &s3)))) return 1;
         }
-        printf("  checksums %s\n", (s0 == s1 && s0 == s2) ? "AGREE" : "DIFFER (a stale read or a protocol bug)");
+        printf("  checksums %s\n", (s0 == s1 && s0 == s2 && s0 == s3) ? "AGREE" : "DIFFER (a stale read or a protocol bug)");
     }
     return 0;
 }
