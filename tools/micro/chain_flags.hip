@@ -10,8 +10,11 @@
 //   mode R1  one launch; plain stores, release fence (buffer_wbl2 sc1), counter += 1; consumers poll the three counters, acquire fence (buffer_inv sc1)
 //   mode R2  one launch; write-through stores (agent-scope atomic stores: sc1), s_waitcnt, counter += 1; consumers poll, then read with sc1 loads
 //   mode R3  one launch, XCD-LOCAL handoff: tiles are dealt to the XCDs in contiguous strips (workgroup w runs on XCD w % 8 and owns tile (w % 8) * T/8 + w / 8), so
-//            the neighbours of an interior tile were produced on the same XCD: plain stores (the L1 writes through to the XCD's L2) + s_waitcnt, counters as L2
-//            atomics, consumers read with sc0 loads (L1 bypassed, L2 hit) — no trip to the memory side.  Only the two tiles at each strip border use the sc1 path.
+//            the neighbours of an interior tile were produced on the same XCD: plain stores (they KEEP the line in the XCD's L2; sc1 stores drop it) + s_waitcnt,
+//            counters as L2 atomics (workgroup scope), consumers read with sc1 loads (L1 bypassed, L2-served: MI355X_MICROARCH.md) — no trip to the memory
+//            side.  Only the two tiles at each strip border store through (sc1).  This mode relies on the OBSERVED placement (blocks b and b + 8 share an XCD),
+//            which HIP does not promise: it prices the hand-off, it is not a protocol to ship; the checksum says whether the placement held.
+//            (A first version polled and read with sc0 loads: those hit the L1 like plain loads, every wait timed out.)
 // Spins are BOUNDED (a timeout sets an error word and falls through): a protocol bug is a wrong checksum, never a hung GPU.  The three modes must
 // produce the same checksum — a stale read across XCDs shows up there.
 // Build: hipcc -O3 --offload-arch=gfx950 chain_flags.hip -o chain_flags ; run on the GPU box: chain_flags [tiles] [layers]
@@ -42,17 +45,6 @@ __device__ __forceinline__ unsigned long long mix(unsigned long long a, unsigned
     return v + (unsigned long long)((int)f & 1);
 }
 
-__device__ __forceinline__ unsigned long long ld_sc0(const unsigned long long* p) {        // group scope: misses the L1, served by this XCD's L2
-    unsigned long long v;
-    asm volatile("global_load_dwordx2 %0, %1, off sc0" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ unsigned ld32_sc0(const unsigned* p) {
-    unsigned v;
-    asm volatile("global_load_dword %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-
 template <int MODE>   // 0: plain loads / stores (one layer per launch); 1: plain + fences; 2: sc1 stores and loads; 3: XCD-local (sc0 loads), sc1 at strip borders
 __device__ __forceinline__ void layer(const Args& a, int l, int t) {
     const int tid = threadIdx.x;
@@ -68,12 +60,9 @@ __device__ __forceinline__ void layer(const Args& a, int l, int t) {
             y = __hip_atomic_load(in + (size_t)t * TILE_U64 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             z = __hip_atomic_load(in + (size_t)tr * TILE_U64 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (MODE == 3) {
-            const int S = a.T / 8, strip = t / S;
-            const bool lx = tl / S != strip, rx = tr / S != strip;                 // that neighbour belongs to another XCD's strip
-            x = lx ? __hip_atomic_load(in + (size_t)tl * TILE_U64 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ld_sc0(in + (size_t)tl * TILE_U64 + k);
-            y = ld_sc0(in + (size_t)t * TILE_U64 + k);
-            z = rx ? __hip_atomic_load(in + (size_t)tr * TILE_U64 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ld_sc0(in + (size_t)tr * TILE_U64 + k);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            x = __hip_atomic_load(in + (size_t)tl * TILE_U64 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // sc1: L1 bypassed, served by the L2
+            y = __hip_atomic_load(in + (size_t)t * TILE_U64 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            z = __hip_atomic_load(in + (size_t)tr * TILE_U64 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             x = in[(size_t)tl * TILE_U64 + k]; y = in[(size_t)t * TILE_U64 + k]; z = in[(size_t)tr * TILE_U64 + k];
         }
@@ -100,9 +89,10 @@ __global__ __launch_bounds__(256) void k_resident(Args a) {
                     const int S_ = a.T / 8;
                     const bool q_border = q % S_ == 0 || q % S_ == S_ - 1;              // border tiles signal (and store) through the memory side
                     const bool local = MODE == 3 && q / S_ == t / S_ && !q_border;
-                    while ((local ? ld32_sc0(c) : __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < a.epoch) {
+                    (void)local;
+                    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.epoch) {
                         __builtin_amdgcn_s_sleep(1);
-                        if (++spins > (1 << 22)) { atomicOr(a.err, 1u); break; }
+                        if (++spins > (1 << 15)) { atomicOr(a.err, 1u); break; }      // ~5 ms: a lost hand-off costs a wrong checksum, not minutes
                     }
                 }
             }
