@@ -546,8 +546,7 @@ def test_graph_replay_matches_eager(dev, model):
 
 
 def test_prefetch_overlaps_the_next_frames_extract_stage_without_changing_results(dev, model):
-    """TCStereo.prefetch: the image-only stage of frame t+1 launched on a second stream beside the refinement of frame t
-    (tcs_mi355/graph.py).  Same kernels on the same data: frame 0 (no splat atomics) must be bit-identical with and without it,
+    """TCStereo.prefetch: the image-only stage of frame t+1 enqueued ahead of time (tcs_mi355/graph.py).  Same kernels on the same data: frame 0 (no splat atomics) must be bit-identical with and without it,
     temporal frames within the atomics' jitter; a prefetch for other images than the next call's is discarded, not used."""
     from tcs_mi355 import synth
     from tcs_mi355.harness import InputPadder
@@ -586,6 +585,43 @@ def test_prefetch_overlaps_the_next_frames_extract_stage_without_changing_result
             assert torch.equal(piped[0], plain[0]) and torch.equal(odd[0], plain[0])
             for t in range(1, len(frames)):
                 assert epe(piped[t], plain[t]) <= 1e-5 and epe(odd[t], plain[t]) <= 1e-5, (graph, t)
+    finally:
+        model.use_hip_graph = saved
+
+
+def test_frame_graph_drop_is_fenced_and_unused_prefetches_age_out(dev, model):
+    """FrameGraphs.drop() releases every captured graph at a safe point and REFUSES while a capture is recording (destroying a HIP graph during
+    another stream's capture aborted the process in round 3); a prefetch nobody consumes gives its slot back after two calls (one
+    mispredicted prefetch must not pin a slot, and with it the two-executable alternation, for the rest of the process)."""
+    from tcs_mi355 import graph as gmod, synth
+    pr_a, pr_b = synth.make_pair(5, height=96, width=128, max_disp=24.0), synth.make_pair(6, height=96, width=128, max_disp=24.0)
+    a1, a2 = D(pr_a.image1, dev)[None], D(pr_a.image2, dev)[None]
+    b1, b2 = D(pr_b.image1, dev)[None], D(pr_b.image2, dev)[None]
+    saved = getattr(model, "use_hip_graph", None)
+    model.use_hip_graph = True
+    try:
+        ref = model(a1, a2, iters=2, test_mode=True)["flow"].clone()
+        fg = model._pipeline()
+        assert fg.rf and fg.ex
+        gmod._CAPTURING += 1
+        try:
+            with pytest.raises(RuntimeError):
+                fg.drop()
+        finally:
+            gmod._CAPTURING -= 1
+        assert fg.rf and fg.ex                                   # nothing was released by the refused call
+        fg.drop()
+        assert not fg.rf and not fg.ex
+        again = model(a1, a2, iters=2, test_mode=True)["flow"]   # re-captures
+        assert torch.equal(again, ref)
+        # a prefetch for images that never come: fresh for one call, aged out by the second
+        model.prefetch(b1, b2, first=True)
+        assert sum(sl.fresh for sl in fg.slots) == 1
+        model(a1, a2, iters=2, test_mode=True)
+        assert sum(sl.fresh for sl in fg.slots) == 1
+        out = model(a1, a2, iters=2, test_mode=True)["flow"]
+        assert sum(sl.fresh for sl in fg.slots) == 0 and all(sl.token is None for sl in fg.slots)
+        assert torch.equal(out, ref)
     finally:
         model.use_hip_graph = saved
 

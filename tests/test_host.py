@@ -399,3 +399,43 @@ def test_kernel_register_budgets():
             assert v <= 128, (nice[k], v)
             seen["gru_q"] += 1
     assert all(n > 0 for n in seen.values()), seen
+
+
+def test_forking_is_switched_off_below_three_hardware_queues():
+    """tcs_mi355/streams.py: with GPU_MAX_HW_QUEUES < 3 the captured frame's parallel launch lists deadlock on ROCm 7.2 (rounds 2-3: no frame
+    completes); the module then runs every frame as one launch list.  Checked in a child interpreter per setting (the switch is read at import)."""
+    import subprocess
+    import sys
+    code = ("import sys, warnings; sys.path.insert(0, %r); import tcs_paths; tcs_paths.add_product_path(); warnings.simplefilter('ignore'); "
+            "from tcs_mi355 import streams; print(int(streams.ENABLED))" % ROOT)
+    for val, want in (("", "1"), ("4", "1"), ("3", "1"), ("2", "0"), ("1", "0"), ("junk", "1")):
+        env = dict(os.environ)
+        env.pop("TCS_MI355_STREAMS", None)
+        if val:
+            env["GPU_MAX_HW_QUEUES"] = val
+        else:
+            env.pop("GPU_MAX_HW_QUEUES", None)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr[-500:]
+        assert out.stdout.strip().splitlines()[-1] == want, (val, out.stdout)
+
+
+def test_lookup_profile_rows_are_selected_by_grid_size(tmp_path):
+    """tools/make_lookup_pmc_json.py on the committed round-3 folds: the four-sequence row must be the BATCHED kernel's (k_corr_lookup<4, 4>,
+    9.25 us in loop position = 0.32 of the roofline), not the one-sequence launches of the same trace's evaluation pass (5.48 us — which round 3
+    divided into four sequences' bytes and reported as 0.54)."""
+    import json
+    import subprocess
+    import sys
+    out = tmp_path / "lk.json"
+    prof = os.path.join(ROOT, "profiles")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_lookup_pmc_json.py"),
+                    "--row", f"one_sequence_640x480:{prof}/r03_bench_kernel_trace_fold.csv:19200",
+                    "--row", f"four_sequences_640x480:{prof}/r03_bench_4seq_kernel_trace_fold.csv:76800",
+                    "--row", f"kitti_375x1242:{prof}/r03_bench_kitti_kernel_trace_fold.csv:29952", "--out", str(out)],
+                   check=True, capture_output=True, timeout=120)
+    d = json.load(open(out))["workloads"]
+    four = d["four_sequences_640x480"]
+    assert "<4, 4>" in four["rocprof_loop_kernel"] and abs(four["rocprof_loop_avg_us"] - 9.254) < 1e-3
+    assert abs(four["frac_rocprof_loop"] - 0.3195) < 2e-3 and abs(four["frac_rocprof_burst"] - 0.4934) < 2e-3
+    assert "<4, 1>" in d["one_sequence_640x480"]["rocprof_loop_kernel"] and "<4, 1>" in d["kitti_375x1242"]["rocprof_loop_kernel"]
