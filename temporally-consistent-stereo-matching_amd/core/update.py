@@ -697,7 +697,7 @@ class DispRefine(nn.Module):
         if GROUP:
             # context_compress (3x3, 192 -> 96 -> 96) beside disp_f_stem (1x1, 27 -> 96 -> 96), layer by layer as grouped launches
             # (the 3x3 halves on the 4-row single-stage tile: a grouped launch allocates the larger LDS size of its two instances)
-            t3 = 101411 if (context_disp.H * context_disp.W >= 10000 and "ctx8" not in _X) else 0
+            t3 = 101411 if context_disp.H * context_disp.W >= 10000 else 0
             with s16.grouped():
                 c = conv16(pool, cc[0], [context_disp, context_grad], act="relu", tile_cfg=t3)
                 d = conv16(pool, ds[0], [f27], act="relu")
