@@ -433,7 +433,8 @@ def test_c2_clip_teacher_forced_vs_oracle_and_domain_flags(dev, oracle, synth_we
 
 def test_e2e_kitti_shape_vs_oracle(dev, oracle, synth_weights, model):
     """BASELINE config 5's shape (KITTI raw 1242x375, padded to 1248x384 by InputPadder): first frame + one temporal
-    frame, 2 iterations, HIP against the CPU oracle through the evaluation harness (un-padded outputs)."""
+    frame at 2 iterations, and the first frame at the configuration's 32 iterations, HIP against the CPU oracle through the evaluation
+    harness (un-padded outputs)."""
     from tcs_mi355 import synth
     from tcs_mi355.harness import run_sequence
     seq = synth.make_sequence(5, n_frames=2, height=375, width=1242, max_disp=192.0)
@@ -445,6 +446,14 @@ def test_e2e_kitti_shape_vs_oracle(dev, oracle, synth_weights, model):
     for t in range(2):
         assert tuple(got[t].shape[-2:]) == (375, 1242)
         assert epe(got[t], want[t]) <= 1e-4, t
+    # ... and the configuration as BASELINE names it — 32 iterations — on the first frame (one oracle frame of this size is ~6 s of CPU):
+    # the north-star bar, 1e-3 EPE
+    one = type(seq)(seq.frames[:1], seq.K, seq.baseline)
+    got32, want32 = [], []
+    run_sequence(model, one, iters=32, device=dev, collect=got32)
+    run_sequence(lambda a, b, **kw: oracle.tc_stereo_forward(synth_weights, a, b, iters=kw["iters"], params=kw["params"]), one, iters=32,
+                 device=torch.device("cpu"), collect=want32)
+    assert epe(got32[0], want32[0]) <= 1e-3, float(epe(got32[0], want32[0]))
 
 
 @pytest.mark.parametrize("name,over", [("separate_fnet", dict(shared_backbone=False)),
