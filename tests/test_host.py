@@ -399,6 +399,12 @@ def test_kernel_register_budgets():
             assert v <= 128, (nice[k], v)
             seen["gru_q"] += 1
     assert all(n > 0 for n in seen.values()), seen
+    # grouped launches (two tile instances behind a branch on the block index): the allocation is the larger of the two bodies' and must
+    # stay at the LINEAR budget, or both halves of a pair lose a wave per SIMD
+    pairs = [k for k in names if nice[k].startswith("void k_conv_s16_pair<")]
+    assert len(pairs) >= 3, [nice[k] for k in pairs]
+    for k in pairs:
+        assert res[k]["vgpr_count"] <= 96, (nice[k], res[k]["vgpr_count"])
 
 
 def test_forking_is_switched_off_below_three_hardware_queues():
