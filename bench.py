@@ -371,8 +371,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch kernels eagerly instead of replaying HIP graphs")
-    ap.add_argument("--no-prefetch", action="store_true",
-                    help="do not start the next frame's image-only stage (feature extraction, correlation pyramid) beside the current frame's loop")
+    ap.add_argument("--prefetch", action="store_true",
+                    help="call TCStereo.prefetch(next frame) after every forward(): the optional video-loop extension (enqueues the next frame's "
+                         "image-only stage ahead of time).  Default OFF since round 4: the headline is exactly the calls evaluate_stereo.py:170-197 makes")
+    ap.add_argument("--no-prefetch", action="store_true", help="(the default; accepted for round-3 command lines)")
     ap.add_argument("--seqs-per-gpu", type=int, default=1,
                     help="independent sequences stacked on the batch dimension of every launch (default 1 = BASELINE configs[1])")
     ap.add_argument("--size", default=None, metavar="HxW",
@@ -380,7 +382,7 @@ def main():
     ap.add_argument("--batched-leg", type=int, default=4,
                     help="after the timed run, also time this many sequences per launch (reported under batched_leg; 0/1 = skip)")
     ap.add_argument("--drop-in-steps", type=int, default=20,
-                    help="frames of the drop-in leg (forward() only, no prefetch call; reported under drop_in_leg; 0 = skip)")
+                    help="frames of the prefetch leg (the headline's clip with TCStereo.prefetch after every forward; reported under prefetch_leg; 0 = skip)")
     ap.add_argument("--kitti-steps", type=int, default=10,
                     help="frames of the KITTI-shape latency leg (375x1242, BASELINE configs[4]; reported under kitti_leg; 0 = skip)")
     ap.add_argument("--tartanair", default=os.environ.get("TCS_TARTANAIR_SEQ", "datasets/TartanAir/abandonedfactory/Easy/P000"),
@@ -397,6 +399,7 @@ def main():
 
     if a.quick:
         a.no_cpu_baseline, a.batched_leg, a.drop_in_steps, a.kitti_steps = True, 0, 0, 0
+    a.no_prefetch = not a.prefetch
     global HEIGHT, WIDTH
     if a.size:
         HEIGHT, WIDTH = (int(v) for v in a.size.lower().split("x"))
@@ -566,12 +569,12 @@ def main():
         batched = {"seqs_per_gpu": a.batched_leg, "error": f"{type(e).__name__}: {e}"}
         ops.LOOKUP_PROBE = None
 
-    # extra leg: exactly the calls evaluate_stereo.py:170-197 makes — forward() per frame, nothing else (no prefetch of the next frame)
+    # extra leg: the same clip WITH the optional TCStereo.prefetch call after every forward() (the headline is without it)
     drop_in = None
-    if rank == 0 and world == 1 and S == 1 and not a.no_prefetch and a.drop_in_steps > 0:
+    if rank == 0 and world == 1 and S == 1 and a.no_prefetch and a.drop_in_steps > 0:
         try:
-            log("drop-in leg: no prefetch call")
-            runner_d = ClipRunner(model, seqs, dev, ITERS, prefetch=False)
+            log("prefetch leg: TCStereo.prefetch(next frame) after every forward()")
+            runner_d = ClipRunner(model, seqs, dev, ITERS, prefetch=True)
             with torch.no_grad():
                 for _ in range(2):
                     runner_d.step()
@@ -583,10 +586,11 @@ def main():
                 td = time.perf_counter() - td
             drop_in = {"value": round(a.drop_in_steps / td, 4), "unit": "stereo-pairs/s", "ms_per_step": round(1e3 * td / a.drop_in_steps, 3),
                        "steps": a.drop_in_steps, "domain_flags": s16.take_flags(),
-                       "what": "TCStereo.forward() per frame only, as evaluate_stereo.py:170-197 calls it (no TCStereo.prefetch)"}
+                       "what": "as the headline plus TCStereo.prefetch(next images) after every forward() (optional video-loop extension: enqueues the "
+                               "next frame's image-only stage ahead of time; hides host launch work only)"}
             del runner_d
         except Exception as e:
-            log(f"drop-in leg failed: {type(e).__name__}: {e}")
+            log(f"prefetch leg failed: {type(e).__name__}: {e}")
             drop_in = {"error": f"{type(e).__name__}: {e}"}
 
     # extra leg: BASELINE configs[4], KITTI-raw frame shape (1242x375 -> padded 1248x384), 32 iterations, per-frame LATENCY: every
@@ -653,14 +657,14 @@ def main():
                                    + " synthetic sequence len=10, D=192, 32 iters, "
                                    + ("one sequence per GPU" if S == 1 else f"{S} independent sequences batched per GPU"),
                        "frames_per_rank": a.steps * S, "seqs_per_gpu": S, "weights": "key-seeded synthetic (tcs_mi355.weights)",
-                       "launch": ("eager" if a.eager else "hip-graph replay") + ("" if a.no_prefetch else
-                                  "; the next frame's image-only stage (features, correlation pyramid) is enqueued right behind the current "
-                                  "frame (TCStereo.prefetch: hides its host-side launch work; on the GPU it does not overlap the loop — DESIGN.md "
-                                  "section 6); drop_in_leg is the same run without that call")},
+                       "launch": ("eager" if a.eager else "hip-graph replay") + ("; forward() per frame only, the calls of evaluate_stereo.py:170-197 "
+                                  "(prefetch_leg: the same with TCStereo.prefetch after every forward)" if a.no_prefetch else
+                                  "; TCStereo.prefetch(next frame) after every forward(): the next frame's image-only stage is enqueued ahead of time "
+                                  "(hides its host-side launch work; on the GPU it does not overlap the loop — DESIGN.md section 6)")},
             "domain_flags": all_flags,
             "gathered_eval_vs_synthetic_gt": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in gathered_eval.items()},
             "roofline": roof, "cpu_baseline": cpu, "epe_vs_oracle_first_frames": epe_vs_oracle, "batched_leg": batched,
-            "drop_in_leg": drop_in, "kitti_leg": kitti, "tartanair_leg": real,
+            "prefetch_leg": drop_in, "kitti_leg": kitti, "tartanair_leg": real,
             "ranks_frames": [int(v[0]) for v in vecs],
             "dist_world_size": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
             "dist_backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
