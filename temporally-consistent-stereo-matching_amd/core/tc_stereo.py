@@ -287,22 +287,18 @@ class TCStereo(nn.Module):
         s16.set_channel(flows_x, motion, 127)
         ub = self.update_block
         ub.begin_frame()
-        from tcs_mi355 import streams as streams_mod
         from tcs_mi355.streams import fork_join, join, mark, spawn
         hu_delta = None              # the hidden-state update of iteration i-1 runs at the head of iteration i's coarse chain
         early32 = None               # gru32 of iteration i + the early share of gru16, launched during iteration i-1
         plain = not a.slow_fast_gru and n3
         # Schedule of one iteration.  The critical chain — blend(i-1) -> hidden-state update -> pool -> gru16's late
         # share -> interp -> gru08 -> flow head -> gradient predictor -> refinement -> blend(i) — is the FIRST branch of every fork, so
-        # that it stays in one launch list of the captured graph (tcs_mi355/streams.py: MAIN_FIRST); what has slack hangs off it as side
+        # that it stays in one launch list of the captured graph (tcs_mi355/streams.py: capture order at a fork); what has slack hangs off it as side
         # branches: [corr lookup -> motion encoder] (needs only coords1 / the flow of the previous blend, due at gru08), and [gru32 of
         # the NEXT iteration -> the share of gru16 that reads only net16 / interp(net32)] (needs net16, due ~500 us later), forked at the
         # iteration's join but enqueued after gru08 / the flow head, so that gru08 and not this branch continues the launch list.
-        # A/B tokens: "encmain" = the encoder chain first and the coarse chain as the side branch (rounds 2-3), "sp_flow" = the early
-        # gru32 branch forks behind the flow head's stencil instead (26.69 against 26.42 ms per frame, three rounds on one box: on this
-        # stack the branch starts ~430 us into the iteration whichever node it hangs off, and the fork at the join is the cheaper one).
-        enc_main = "encmain" in _X
-        sp_join = "sp_flow" not in _X
+        # (Measured alternatives, profiles/r04_ab_logs.txt: the encoder chain as the first branch +1.3 ms; the early gru32 branch forked behind the
+        # flow head's stencil instead of at the join +0.27 ms — on this stack the branch starts ~430 us into the iteration whichever node it hangs off.)
         for itr in range(iters):
             def enc_branch():
                 corr = corr_fn(coords1)
@@ -321,21 +317,13 @@ class TCStereo(nn.Module):
 
             up32_now = join(early32)                     # (None on the first iteration: gru32 then runs inside the coarse branch)
             early32 = None
-            if enc_main:
-                (corr, m), up16 = fork_join([enc_branch, coarse_branch], site="iter")
-            else:
-                up16, (corr, m) = fork_join([coarse_branch, enc_branch], site="iter")
+            up16, (corr, m) = fork_join([coarse_branch, enc_branch], site="iter")
             run_ahead = plain and trace is None and itr + 1 < iters
             # net16 is final for this iteration: gru32 of the NEXT iteration + gru16's early share (update.py) may start from here
             def ahead():
                 up32 = ub.run_gru32(pool, nets, inp_list)
                 return (up32, ub.gru16_early(pool, nets, inp_list, up32)) if "nog16split" not in _X else up32
-            at_join = None
-            if run_ahead and sp_join:
-                if streams_mod.MAIN_FIRST:
-                    at_join = mark()
-                else:
-                    early32 = spawn(ahead, site="gru32")           # rounds 2-3: enqueued before gru08 ("sidefirst,encmain,sp_join")
+            at_join = mark() if run_ahead else None                # forked HERE, enqueued behind gru08 / the flow head (never the join's first child)
             sums = getattr(self, "_checksums", None)       # debugging hook (tools/determinism_check.py): device-side sums, no sync
             lazy = trace is None and sums is None           # the hooks want the flow head's / residual head's outputs as tensors
             delta_flow = ub.run_fine(pool, nets, inp_list, m, up16, lazy=lazy)
@@ -348,15 +336,12 @@ class TCStereo(nn.Module):
                 disp_q, g5, cands = s16.flow_taps_step_grads(coords1, delta_flow, scale=5.0)
             else:
                 disp_q, g5, cands = ops.flow_step_grads(coords1, delta_flow, scale=5.0)
-            at_flow = mark() if (run_ahead and not sp_join) else None
             disp_grad, context = self.disp_grad_refine.run(pool, g5, cands, dg_pre, lazy=lazy, slot=itr if itr < IN_SUM_SLOTS else None)
             last = itr == iters - 1
             # (not on the last iteration: no lookup follows; "nowarm": A/B)
             warm = corr_fn._pyr if (not last and "nowarm" not in _X and a.corr_levels == 4) else None
             refined, up_mask, fused = self.disp_refine.run(pool, disp_grad, disp_q, nets[0], context, want_mask=last, motion=motion,
                                                            warm_pyramid=warm, warm_radius=a.corr_radius)
-            if run_ahead and not sp_join:
-                early32 = spawn(ahead, site="gru32", after=at_flow)     # enqueued last: never the first child of its fork point
             hu_delta = fused["delta_disp"]
             coords1, flows_x = fused["coords1"], fused["flow_x"]
             if sums is not None:

@@ -130,7 +130,7 @@ def pool_of(module) -> s16.S16Pool:
 # A/B switches for benchmarking sessions (tools/, gpurun logs): comma-separated tokens in TCS_MI355_X.  Never set in production.
 _X = set(t for t in os.environ.get("TCS_MI355_X", "").split(",") if t)
 # Independent layer pairs as ONE grouped launch (tcs_conv2d_s16_group / tcs_conv2d_group) instead of two branches of the captured graph;
-# "nogroup" (A/B): the round-3 forks (stems, refine) resp. two launches in a row (encoder).
+# "nogroup" (A/B): two launches in a row.
 GROUP = "nogroup" not in _X
 
 
@@ -530,7 +530,7 @@ class BasicMultiUpdateBlock(nn.Module):
         if not iter08:
             self.run_coarse(pool, net, inp, iter16, iter32, want_up16=False)
             return None
-        # the coarse GRUs first (the longer chain stays in the launch list, streams.MAIN_FIRST), the motion encoder beside them
+        # the coarse GRUs first (the longer chain stays in the launch list, tcs_mi355/streams.py), the motion encoder beside them
         up16, m = fork_join([lambda: self.run_coarse(pool, net, inp, iter16, iter32),
                              lambda: self.encoder.run(pool, flow, corr, motion)], site="coarse")
         return self.run_fine(pool, net, inp, m, up16, update)
@@ -611,18 +611,14 @@ class DispGradPredictor(nn.Module):
             return conv16(pool, conv, srcs, act="relu", addend=share, pc=packed16_part(conv, ((0, n),), with_bias=False))
 
         gs, cs = self.conv_grad_stem, self.conv_grad_candidate_stem
-        if GROUP:
-            # the two stems (update.py:200-205) layer by layer as grouped launches: [2 -> 32 | 32 -> 64] on the fp32-MFMA kernel (the
-            # candidates are unbounded; the gradient stem rides the same instance), then [32 -> 32 | 64 -> 64] on S16 — no fork, no join
-            with ops.grouped():
-                g1 = conv32to16(pool, gs[0], g5, act="relu")
-                c1 = conv32to16(pool, cs[0], cands, act="relu")
-            with s16.grouped():
-                x4_grad = conv16(pool, gs[2], [g1])
-                x4_cand = conv16(pool, cs[2], [c1])
-        else:
-            x4_cand, x4_grad = fork_join([lambda: conv16(pool, cs[2], [conv32to16(pool, cs[0], cands, act="relu")]),
-                                          lambda: conv16(pool, gs[2], [conv32to16(pool, gs[0], g5, act="relu")])], site="stems")
+        # the two stems (update.py:200-205) layer by layer as grouped launches: [2 -> 32 | 32 -> 64] on the fp32-MFMA kernel (the candidates are
+        # unbounded; the gradient stem rides the same instance), then [32 -> 32 | 64 -> 64] on S16 — no fork, no join
+        with ops.grouped(enabled=GROUP):
+            g1 = conv32to16(pool, gs[0], g5, act="relu")
+            c1 = conv32to16(pool, cs[0], cands, act="relu")
+        with s16.grouped(enabled=GROUP):
+            x4_grad = conv16(pool, gs[2], [g1])
+            x4_cand = conv16(pool, cs[2], [c1])
         x4 = feat(self.conv_4_4[0], [x4_grad, x4_cand], pre[0])
         x8 = conv16(pool, self.conv_4_8[0], [x4], act="relu")                    # 3x3 stride 2
         x8 = feat(self.conv_8_8[0], [x8], pre[1])
@@ -694,19 +690,15 @@ class DispRefine(nn.Module):
             f27, cand9 = s16.propagate_disparity(disp_grads, disp, out16=f27)
 
         cc, ds = self.context_compress, self.disp_f_stem
-        if GROUP:
-            # context_compress (3x3, 192 -> 96 -> 96) beside disp_f_stem (1x1, 27 -> 96 -> 96), layer by layer as grouped launches
-            # (the 3x3 halves on the 4-row single-stage tile: a grouped launch allocates the larger LDS size of its two instances)
-            t3 = 101411 if context_disp.H * context_disp.W >= 10000 else 0
-            with s16.grouped():
-                c = conv16(pool, cc[0], [context_disp, context_grad], act="relu", tile_cfg=t3)
-                d = conv16(pool, ds[0], [f27], act="relu")
-            with s16.grouped():
-                context = conv16(pool, cc[2], [c], tile_cfg=t3)
-                disp_f = conv16(pool, ds[2], [d])
-        else:
-            context, disp_f = fork_join([lambda: conv16(pool, cc[2], [conv16(pool, cc[0], [context_disp, context_grad], act="relu")]),
-                                         lambda: conv16(pool, ds[2], [conv16(pool, ds[0], [f27], act="relu")])], site="refine")
+        # context_compress (3x3, 192 -> 96 -> 96) beside disp_f_stem (1x1, 27 -> 96 -> 96), layer by layer as grouped launches
+        # (the 3x3 halves on the 4-row single-stage tile: a grouped launch allocates the larger LDS size of its two instances)
+        t3 = 101411 if context_disp.H * context_disp.W >= 10000 else 0
+        with s16.grouped(enabled=GROUP):
+            c = conv16(pool, cc[0], [context_disp, context_grad], act="relu", tile_cfg=t3)
+            d = conv16(pool, ds[0], [f27], act="relu")
+        with s16.grouped(enabled=GROUP):
+            context = conv16(pool, cc[2], [c], tile_cfg=t3)
+            disp_f = conv16(pool, ds[2], [d])
         fused = conv16(pool, self.conv_fuse[0], [disp_f, context], act="relu")
         fused = conv16(pool, self.conv_fuse[2], [fused], act="relu")
         w = conv16(pool, self.w_head[0], [fused], act="relu")

@@ -29,12 +29,9 @@ from typing import Callable, Dict, List, Optional
 import torch
 
 _CAPTURING = 0          # > 0 while any FrameGraphs capture is recording (FrameGraphs.drop refuses then)
-# Where EXTRACT is enqueued.  A second stream cannot make it overlap the loop on this stack (module docstring) and costs a hole: the
-# stage's first kernel started 0.3-0.7 ms after the previous frame's last one (profiles/r04_frame_phases*.txt) although its
-# dependencies had been met 20 ms earlier — a queue that sat behind an unsatisfied barrier packet is picked up late.  On the CALLER's
-# stream the stage follows the previous frame's last kernel directly; a prefetch then only moves the host's launch work ahead.
-# A/B token "xsx" (TCS_MI355_X): the second stream of round 3.
-_EXTRACT_ON_MAIN = "xsx" not in set(os.environ.get("TCS_MI355_X", "").split(","))
+# EXTRACT is enqueued on the CALLER's stream.  Rounds 3's second stream could not make it overlap the loop on this stack (module docstring) and
+# measured the same (profiles/r04_ab_logs.txt, r4_k); on the caller's stream there are no cross-stream waits to get wrong, and a prefetch
+# only moves the host's launch work ahead.
 
 
 def _flatten(temporal):
@@ -238,21 +235,13 @@ class FrameGraphs:
         called), only after that frame's head: the extraction then overlaps its loop."""
         slot = self.slots[si]
         main = torch.cuda.current_stream()
-        sx = main if _EXTRACT_ON_MAIN else self._stream(image1.device)
+        sx = main
         key = self._ex_key(image1, first)
         entries = None
         if use_graph:
             if key not in self.ex:
                 self.ex[key] = self._capture_extract(key, image1, image2, first)
             entries = self.ex[key]
-        if sx is not main:
-            if inputs_ready:
-                sx.wait_event(self.loop_start)
-            else:
-                here = torch.cuda.Event()
-                here.record(main)
-                sx.wait_event(here)
-            sx.wait_event(slot.free)
         with torch.cuda.stream(sx):
             if entries is not None:
                 e = entries[si]

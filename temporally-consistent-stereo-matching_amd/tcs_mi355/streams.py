@@ -19,10 +19,11 @@ from typing import Callable, List, Sequence
 import torch
 
 def _hw_queues_allow_forks() -> bool:
-    """A captured frame with parallel branches needs >= 3 hardware queues.  ROCm's graph executor submits each launch list in batches
-    of consecutive nodes, and a batch of the main list can contain a wait for a side-list node that is submitted after it: on separate
-    hardware queues that is a pending barrier packet, on ONE in-order queue (or when two lists that wait for each other share one of two)
-    it is a deadlock — with GPU_MAX_HW_QUEUES=1 or 2 no frame ever completed (profiles/r03_ab_logs.txt).  ROCclr's default is 4; when
+    """A captured frame with parallel branches needs >= 3 hardware queues: with GPU_MAX_HW_QUEUES=1 or 2 no frame ever completed
+    (profiles/r03_ab_logs.txt; the stall is in replay and needs parallel launch lists).  Most likely cause (inferred — the executor's source
+    is not available here): the lists of a replayed graph are fed to their queues in batches of consecutive nodes, and a
+    batch of the main list can contain a wait for a side-list node that is submitted after it: a pending barrier packet on separate hardware
+    queues, a deadlock when the lists share one in-order queue.  ROCclr's default is 4; when
     the environment asks for fewer, forking is switched off (one launch list: correct on any queue count, ~2 ms per frame slower)."""
     v = os.environ.get("GPU_MAX_HW_QUEUES", "").strip()
     if not v:
@@ -44,11 +45,10 @@ OFF = set(t for t in os.environ.get("TCS_MI355_FORK_OFF", "").split(",") if t)  
 # Capture order at a fork.  ROCm's graph executor cuts a captured graph into launch lists by a depth-first walk that follows a node's
 # FIRST captured child: that child stays in its parent's list (same hardware queue, ~1.5 us boundary), every later child starts a
 # new list whose first node waits for the parent across queues (~10 us) and whose last node the join waits for across queues
-# again.  MAIN_FIRST (default): the branch given first to fork_join — by convention the one on the iteration's critical chain —
+# again.  The branch given first to fork_join — by convention the one on the iteration's critical chain —
 # is enqueued BEFORE the side branches (which wait for an event recorded at the fork point), so the critical chain never
-# leaves its queue and the side branches, which have slack, absorb the cross-queue latencies.  "sidefirst" in TCS_MI355_X restores
-# the round-2/3 order (side branches first) for A/B runs.
-MAIN_FIRST = "sidefirst" not in set(os.environ.get("TCS_MI355_X", "").split(","))
+# leaves its queue and the side branches, which have slack, absorb the cross-queue latencies.  (Rounds 2-3 enqueued the side branches
+# first; measured against each other in profiles/r04_ab_logs.txt.)
 _POOL: dict = {}
 _DEPTH = 0          # nesting level of fork_join: each level owns its own side streams (a nested fork must never
                     # pick the stream it is already running on)
@@ -106,7 +106,7 @@ def spawn(fn: Callable[[], object], site: str = "", slot: int = 0, after=None) -
     current stream wait for it.  Used for work whose result is needed much later (the next iteration's gru32).  Spawns that
     are in flight at the same time take different `slot`s (one stream each).  `after` (a `mark()`): the side chain starts
     behind THAT point of the current stream instead — work enqueued on the current stream since then neither delays it nor, under
-    capture, loses its place as the first child of the fork point (see MAIN_FIRST)."""
+    capture, loses its place as the first child of the fork point (see "Capture order at a fork" above)."""
     global _IN_SIDE, _DEPTH
     if not ENABLED or _IN_SIDE > 0 or not torch.cuda.is_available() or ("all" not in SITES and site not in SITES) or site in OFF:
         return Spawned(fn(), None)
@@ -151,23 +151,17 @@ def fork_join(fns: Sequence[Callable[[], object]], site: str = "") -> list:
     results = [None] * len(fns)
     _DEPTH += 1
     try:
-        if MAIN_FIRST:
-            here = torch.cuda.Event()
-            here.record(cur)
-            results[0] = fns[0]()
+        here = torch.cuda.Event()
+        here.record(cur)
+        results[0] = fns[0]()
         for i, st in enumerate(sides, start=1):
-            if MAIN_FIRST:
-                st.wait_event(here)
-            else:
-                st.wait_stream(cur)
+            st.wait_event(here)
             _IN_SIDE += 1
             try:
                 with torch.cuda.stream(st):
                     results[i] = fns[i]()
             finally:
                 _IN_SIDE -= 1
-        if not MAIN_FIRST:
-            results[0] = fns[0]()
     finally:
         _DEPTH -= 1
     for st in sides:
